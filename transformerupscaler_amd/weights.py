@@ -1,0 +1,108 @@
+"""Parameter inventory and deterministic synthetic weights for FastTransformer.
+
+Key names / shapes mirror the reference ``state_dict`` (SURVEY.md §8(b);
+reference models/FastTransformer/model.py:189-229, utils.py:54-91) so that checkpoints
+interchange.  There is no network here, so benchmarks, fixtures and tests use weights
+from a closed-form seeded formula instead of a trained checkpoint.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+IN_CH, BASE, DIM, BLOCKS, HEADS, MLP, WINDOW = 3, 64, 192, 6, 12, 768, 8
+VALID_SCALES = (2, 3, 4, 6)
+
+
+def upsampler_layout(scale: int):
+    """[(sequential index, r)] of the conv+PixelShuffle stages of one scale (utils.py:54-91)."""
+    if scale == 2:
+        return [(0, 2)]
+    if scale == 4:
+        return [(0, 2), (2, 2)]
+    if scale in (3, 6):
+        return [(0, scale)]
+    raise ValueError(f"Requested scale={scale} was not built.")
+
+
+def param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["conv1.weight"] = (BASE, IN_CH, 3, 3); s["conv1.bias"] = (BASE,)
+    s["conv2.weight"] = (BASE, BASE, 3, 3); s["conv2.bias"] = (BASE,)
+    for pre, nf in (("up1", BASE), ("final_upscale", IN_CH)):
+        if pre == "final_upscale":
+            s["up1_conv.conv.weight"] = (IN_CH, BASE, 3, 3)
+        for sc in VALID_SCALES:
+            for idx, r in upsampler_layout(sc):
+                s[f"{pre}.upsamplers.{sc}.{idx}.weight"] = (nf * r * r, nf, 3, 3)
+                s[f"{pre}.upsamplers.{sc}.{idx}.bias"] = (nf * r * r,)
+    s["final_upscale_conv.weight"] = (IN_CH, IN_CH, 3, 3); s["final_upscale_conv.bias"] = (IN_CH,)
+    s["patch_embed.weight"] = (DIM, BASE, 8, 8); s["patch_embed.bias"] = (DIM,)
+    for i in range(BLOCKS):
+        p = f"window_blocks.{i}"
+        s[p + ".norm1.weight"] = (DIM,); s[p + ".norm1.bias"] = (DIM,)
+        s[p + ".attn.relative_position_bias_table"] = ((2 * WINDOW - 1) ** 2, HEADS)
+        s[p + ".attn.qkv.weight"] = (3 * DIM, DIM); s[p + ".attn.qkv.bias"] = (3 * DIM,)
+        s[p + ".attn.proj.weight"] = (DIM, DIM); s[p + ".attn.proj.bias"] = (DIM,)
+        s[p + ".norm2.weight"] = (DIM,); s[p + ".norm2.bias"] = (DIM,)
+        s[p + ".mlp.0.weight"] = (MLP, DIM); s[p + ".mlp.0.bias"] = (MLP,)
+        s[p + ".mlp.2.weight"] = (DIM, MLP); s[p + ".mlp.2.bias"] = (DIM,)
+    s["patch_unembed.weight"] = (DIM, BASE, 8, 8); s["patch_unembed.bias"] = (BASE,)
+    s["decoder_conv1.weight"] = (BASE, BASE, 3, 3); s["decoder_conv1.bias"] = (BASE,)
+    s["decoder_conv2.weight"] = (IN_CH, BASE, 3, 3); s["decoder_conv2.bias"] = (IN_CH,)
+    return s
+
+
+def active_param_names(scale: int):
+    """Parameters that receive a gradient when training at one fixed scale."""
+    names = []
+    for k in param_shapes():
+        if ".upsamplers." in k:
+            if int(k.split(".upsamplers.")[1].split(".")[0]) != scale:
+                continue
+        names.append(k)
+    return names
+
+
+def _fan_in(name: str, shape) -> int:
+    if name == "patch_unembed.weight":      # ConvTranspose2d: weight (in, out, kh, kw)
+        return shape[1] * shape[2] * shape[3]
+    if len(shape) == 4:
+        return shape[1] * shape[2] * shape[3]
+    if len(shape) == 2:
+        return shape[1]
+    return 0
+
+
+def deterministic_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded closed-form weights: uniform(+-1/sqrt(fan_in)) matrices (PyTorch's default
+    Conv/Linear scale), LayerNorm gamma 1+-0.1 / beta +-0.1, rel-pos table N(0, 0.5) so the
+    bias path is numerically visible, and a +0.5 offset on the last bias so outputs straddle
+    the [0,1] clamp instead of saturating at 0."""
+    sd: Dict[str, torch.Tensor] = OrderedDict()
+    shapes = param_shapes()
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) & 0x7FFFFFFF)
+        if name.endswith("relative_position_bias_table"):
+            t = torch.randn(shape, generator=g) * 0.5
+        elif ".norm" in name and name.endswith("weight"):
+            t = 1.0 + (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif ".norm" in name:
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif name.endswith("bias"):
+            wname = name[:-4] + "weight"
+            bound = 1.0 / math.sqrt(_fan_in(wname, shapes[wname]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            if name == "final_upscale_conv.bias":
+                t = t + 0.5
+        else:
+            bound = 1.0 / math.sqrt(_fan_in(name, shape))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            if name in ("up1_conv.conv.weight", "final_upscale_conv.weight"):
+                t = t * 3.0     # widen the output spread so both clamp edges are exercised
+        sd[name] = t.to(dtype)
+    return sd

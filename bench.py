@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""Headline benchmark: FastTransformer 2x 720p->1080p bf16 inference, batch 8 per GPU (BASELINE.json
+configs[1]); one "step" = one forward pass of the hot path over one batch of synthetic images that
+are already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Inference shards by images with no data-path collective (replicas, weak scaling).  Prints ONE JSON
+line on rank 0 (contract in the task statement), including the roofline of the dominant kernel
+(the 64->256 up-conv, MFMA-bound) measured live with events on the launch stream, and the CPU
+baseline (the oracle = CPU restatement of the reference, "port") on a bounded sample.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+LR_H, LR_W, OUT = 720, 1280, (1080, 1920)
+UPCONV_FLOP_PER_IMAGE = 2.0 * LR_H * LR_W * 256 * 576      # 271.8 GFLOP / image
+
+
+def cpu_baseline(batch_images: int):
+    """Oracle (CPU restatement of the reference path) on the host cores, B=1, same synthetic input."""
+    from oracle import fast_transformer_oracle as O
+    from transformerupscaler_amd.weights import deterministic_state_dict
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = deterministic_state_dict(0)
+    x = torch.rand((1, 3, LR_H, LR_W), generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        O.forward(sd, x, res_out=OUT)                 # warm-up
+        n, t0 = 0, time.time()
+        while n < 3 or (time.time() - t0 < 10.0 and n < 8):
+            O.forward(sd, x, res_out=OUT)
+            n += 1
+        dt = time.time() - t0
+    return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} forward passes of 1 image 720x1280 -> 1080x1920 fp32 after 1 warm-up (torch CPU, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    import importlib
+    from transformerupscaler_amd import engine
+    from transformerupscaler_amd.weights import deterministic_state_dict
+    model = importlib.import_module("models.FastTransformer.model").TransformerModel()
+    model.load_state_dict(deterministic_state_dict(0), strict=False)
+    model = model.to(dev).eval()
+
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.rand((args.batch, 3, LR_H, LR_W), generator=g).to(dev)      # resident in HBM before timing
+
+    events = []
+
+    @contextlib.contextmanager
+    def timer(name):
+        if name != "up1.0" or not timing_on[0]:
+            yield
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()                       # current stream == the stream the kernel is launched on
+        yield
+        e.record()
+        events.append((s, e))
+
+    timing_on = [False]
+    engine.stage_timer = timer
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(x, res_out=OUT)
+        torch.cuda.synchronize()
+        barrier()
+        timing_on[0] = True
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x, res_out=OUT)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+    timing_on[0] = False
+    assert tuple(y.shape) == (args.batch, 3) + OUT
+
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
+    achieved = UPCONV_FLOP_PER_IMAGE * args.batch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec, FastTransformer 2x 720p->1080p inference",
+            "value": world * args.batch * args.steps / dt,
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "FastTransformer 2x 720x1280 -> res_out 1080x1920, bf16 inference, "
+                                   f"batch {args.batch} per GPU (BASELINE.json configs[1])",
+                       "images_per_gpu_per_step": args.batch, "parallelism": f"replicas x{world}",
+                       "weights": "deterministic synthetic (transformerupscaler_amd.weights, seed 0)"},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_c64_kernel<4,0> (up1 64->256 + PixelShuffle)",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "ms_per_launch": kern_ms, "launches_timed": len(events)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.batch)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None     # measured on rank 0 at N=1 only (see BENCH at n_gpus=1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

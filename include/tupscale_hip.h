@@ -1,0 +1,98 @@
+/* C ABI of libtupscale_hip.so -- the MI355X (gfx950) kernels behind the FastTransformer
+ * plugin surface (models/FastTransformer/model.py: TransformerModel).
+ *
+ * The reference has no native layer: its hot path is a chain of PyTorch aten calls inside
+ * nn.Module.forward.  Each entry point below replaces the aten call site(s) cited next to it
+ * (reference file:line, relative to the reference repo root).  A binding needs only plain
+ * pointers to device memory, ints and a hipStream_t (passed as void*); no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a hipError_t value; launches are asynchronous on
+ *     `stream` (pass the caller's current stream, never assume the null stream);
+ *   - bf16 tensors are raw uint16 storage; NHWC = [B][H][W][C] with C = 64;
+ *   - "window layout" = token rows ordered [B][window_y][window_x][8*8 tokens], 192 features,
+ *     the order window_partition (model.py:31-45) produces, including zero rows for the
+ *     tokens added by the bottom/right padding (model.py:273-280);
+ *   - packed weights are produced by transformerupscaler_amd/packing.py (layouts documented
+ *     at each function).
+ */
+#ifndef TUPSCALE_HIP_H
+#define TUPSCALE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library / ABI version, bumped when a signature changes */
+int tup_abi_version(void);
+
+/* conv1: Conv2d(3,64,k3,p1)+ReLU. model.py:202-203,251.
+ * x fp32 [B][3][H][W]; wp bf16 [64][32] (row ct*16+4g+e = channel g*16+ct*4+e, k = tap*3+cin,
+ * zero pad 27..31); bias fp32 [64]; out bf16 NHWC. */
+int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* bias, void* out,
+                       int B, int H, int W, int relu, void* stream);
+
+/* Conv2d(64, Cout, k3, p1) on NHWC bf16:
+ *   conv2 model.py:204,252 | decoder_conv1 model.py:228,312 | Upsampler convs + PixelShuffle(r)
+ *   utils.py:62-63,74-75,83-84 (out_mode 0, ntiles = r*r, the cout tile index is the sub-pixel
+ *   i*r+j) | up1_conv utils.py:32-40 and decoder_conv2 model.py:229,313 (out_mode 1).
+ * wp bf16 [ntiles][9][rows][64]; out_mode 0: rows = 64, bias fp32 [ntiles][64] or NULL,
+ * out bf16 [B][H*r][W*r][64]; out_mode 1: rows = 16 (cout_valid real), bias fp32 [cout_valid]
+ * or NULL, out fp32 [B][cout_valid][H][W]. */
+int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* bias, void* out,
+                        int B, int H, int W, int ntiles, int r, int cout_valid,
+                        int relu, int out_mode, void* stream);
+
+/* Planar fp32 Conv2d(3, 3*r*r, k3, p1) + PixelShuffle(r) [+ add] [+ clamp(0,1)]:
+ *   final_upscale utils.py:62-63,74-75,83-84 (n_feats=3) | final_upscale_conv model.py:212,317
+ *   fused with "out = upscaled_input + residual_up" model.py:320 and torch.clamp model.py:327.
+ * x fp32 [B][3][H][W]; w28 fp32 [3*r*r][28] (27 taps (cin,ky,kx) + pad); out/add fp32 [B][3][H*r][W*r]. */
+int tup_conv3x3_planar_fwd(const float* x, const float* w28, const float* bias, const float* add,
+                           float* out, int B, int H, int W, int r, int clamp01, void* stream);
+
+/* transforms.Resize on a tensor = antialiased bilinear (model.py:323-325, train.py:127-130)
+ * [+ clamp(0,1) model.py:327].  Tap tables as aten's _compute_indices_weights_aa (float32). */
+int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, const int* ysize, const float* yw,
+                      int KY, const int* xmin, const int* xsize, const float* xw, int KX, int planes,
+                      int Hi, int Wi, int Ho, int Wo, int clamp01, void* stream);
+
+/* torch.clamp(out, 0, 1) model.py:327 when no resize precedes it. */
+int tup_clamp01_fwd(const float* in, float* out, long long n, void* stream);
+
+/* nn.LayerNorm(192) model.py:142,144,163,169.  x fp32 [M][192] -> y bf16 [M][192];
+ * mean/rstd fp32 [M] optional (saved for backward). */
+int tup_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int M, void* stream);
+
+/* relative_position_bias_table[relative_position_index] model.py:120-123 -> dense per-head bias
+ * in the attention kernel's fragment order, fp32 [12][4][4][64][4]. */
+int tup_relpos_bias_expand(const float* table, float* frag, void* stream);
+
+/* WindowAttention core model.py:114-130 (q*scale, qk^T + bias, softmax, @v, head concat).
+ * qkv bf16 [nwin][64][576]; out bf16 [nwin][64][192]. */
+int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, void* stream);
+
+/* nn.Linear family model.py:79,81,146-151 with fused epilogues.
+ * Wt bf16 [N][K] (rows permuted per 64-group: row ct*16+4g+e = feature g*16+ct*4+e), bias fp32 [N].
+ * a_dtype 0: A bf16 [M][lda]; 1: A fp32.  epilogue 0: +bias -> bf16 | 1: +bias, erf-GELU -> bf16
+ * (model.py:148) | 2: +bias + res -> fp32 (residual adds model.py:164,171). */
+int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
+                        const float* res, void* out, int ldo, int M, int N, int K, int epilogue,
+                        void* stream);
+
+/* reflect pad + patch_embed Conv2d(64,192,k8,s8) + NHWC permute + zero token pad +
+ * window_partition: model.py:256-261,268-285.  feat bf16 NHWC; Wt bf16 [192][4096],
+ * k = (i*8+j)*64+c; x_out fp32 window layout. */
+int tup_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, float* x_out,
+                        int B, int H, int W, void* stream);
+
+/* window_reverse + crop + patch_unembed ConvTranspose2d(192,64,k8,s8) + crop + skip add:
+ * model.py:292-309.  x fp32 window layout; Wt bf16 [4096][192], n = (i*8+j)*64+o; bias fp32 [64];
+ * skip/out bf16 NHWC [B][H][W][64]. */
+int tup_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip,
+                          void* out, int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUPSCALE_HIP_H */

@@ -1,0 +1,169 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against the torch-CPU restatement of the
+aten op it replaces (oracle side), on bf16-rounded operands.  Integer/index work (window layout,
+pixel shuffle, padding) is checked exactly through values; floating point within bf16 tolerances
+stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fast_transformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rnd(shape, seed, scale=1.0, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale + shift
+
+
+def close(a, b, atol, rtol, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    assert bool((err <= bound).all()), f"{what}: max err {err.max().item():.3e}, worst ratio {(err / bound).max().item():.2f}"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from transformerupscaler_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 37, 70), (1, 3, 8, 32), (1, 3, 64, 96)])
+def test_conv1(dev, shape):
+    from transformerupscaler_amd import ops, packing
+    x = rnd(shape, 1, 0.5, 0.5)
+    w, b = rnd((64, 3, 3, 3), 2, 0.3), rnd((64,), 3, 0.2)
+    ref = F.relu(F.conv2d(bf(x), bf(w), b, padding=1)).permute(0, 2, 3, 1)
+    got = ops.conv1(x.to(dev), packing.pack_conv1(w).to(dev), b.to(dev), relu=True)
+    close(got, ref, 1e-2, 1e-2, "conv1")
+
+
+@pytest.mark.parametrize("r,hw", [(1, (19, 45)), (2, (16, 64)), (3, (9, 33)), (6, (8, 20)), (1, (8, 32))])
+def test_conv_c64_pixelshuffle(dev, r, hw):
+    from transformerupscaler_amd import ops, packing
+    H, W = hw
+    x = bf(rnd((2, 64, H, W), 4))
+    w, b = rnd((64 * r * r, 64, 3, 3), 5, 0.06), rnd((64 * r * r,), 6, 0.2)
+    ref = F.pixel_shuffle(F.conv2d(x, bf(w), b, padding=1), r).permute(0, 2, 3, 1)
+    wp, bp = packing.pack_conv_c64(w, b, r)
+    got = ops.conv_c64(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev), wp.to(dev), bp.to(dev), r, relu=False)
+    assert tuple(got.shape) == (2, H * r, W * r, 64)
+    close(got, ref, 1.5e-2, 1e-2, f"conv_c64 r={r}")
+    got = ops.conv_c64(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev), wp.to(dev), bp.to(dev), r, relu=True)
+    close(got, F.relu(ref), 1.5e-2, 1e-2, f"conv_c64 relu r={r}")
+
+
+@pytest.mark.parametrize("co,bias,relu", [(3, False, True), (3, True, False)])
+def test_conv_c64_thin(dev, co, bias, relu):
+    from transformerupscaler_amd import ops, packing
+    x = bf(rnd((2, 64, 21, 50), 7))
+    w = rnd((co, 64, 3, 3), 8, 0.06)
+    b = rnd((co,), 9, 0.2) if bias else None
+    ref = F.conv2d(x, bf(w), b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    got = ops.conv_c64_thin(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev), packing.pack_conv_c64_thin(w).to(dev),
+                            None if b is None else b.to(dev), co, relu=relu)
+    close(got, ref, 2e-4, 1e-4, "thin conv (fp32 out)")
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 6])
+def test_conv_planar(dev, r):
+    from transformerupscaler_amd import ops, packing
+    x = rnd((2, 3, 23, 70), 10)
+    w, b = rnd((3 * r * r, 3, 3, 3), 11, 0.3), rnd((3 * r * r,), 12, 0.2)
+    ref = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), r)
+    got = ops.conv_planar(x.to(dev), packing.pack_planar(w).to(dev), b.to(dev), r)
+    close(got, ref, 2e-6, 1e-5, "planar conv")
+    add = rnd(tuple(ref.shape), 13)
+    got = ops.conv_planar(x.to(dev), packing.pack_planar(w).to(dev), b.to(dev), r, add=add.to(dev), clamp=True)
+    close(got, (ref + add).clamp(0, 1), 2e-6, 1e-5, "planar conv + add + clamp")
+
+
+@pytest.mark.parametrize("sizes", [((72, 96), (54, 72)), ((64, 64), (48, 48)), ((30, 40), (45, 47)), ((144, 256), (108, 192))])
+def test_resize_aa(dev, sizes):
+    from transformerupscaler_amd import ops
+    (h, w), (oh, ow) = sizes
+    x = rnd((2, 3, h, w), 14, 0.8, 0.5)
+    got = ops.resize_aa(x.to(dev), (oh, ow), clamp=False)
+    close(got, O.aa_resize(x, (oh, ow)), 3e-6, 0, "resize")
+    got = ops.resize_aa(x.to(dev), (oh, ow), clamp=True)
+    close(got, O.aa_resize(x, (oh, ow)).clamp(0, 1), 3e-6, 0, "resize+clamp")
+    close(ops.clamp01(x.to(dev)), x.clamp(0, 1), 0, 0, "clamp")
+
+
+def test_layernorm(dev):
+    from transformerupscaler_amd import ops
+    x = rnd((200, 192), 15, 2.0, 0.3)
+    gm, bt = rnd((192,), 16, 0.1, 1.0), rnd((192,), 17, 0.1)
+    y, mean, rstd = ops.layernorm(x.to(dev), gm.to(dev), bt.to(dev), save_stats=True)
+    close(y, F.layer_norm(x, (192,), gm, bt, 1e-5), 1e-2, 8e-3, "layernorm")
+    close(mean, x.mean(1), 1e-5, 1e-5, "mean")
+    close(rstd, 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5), 1e-5, 1e-5, "rstd")
+
+
+@pytest.mark.parametrize("M,N,K", [(192, 576, 192), (320, 192, 768), (128, 768, 192)])
+def test_gemm_tokens(dev, M, N, K):
+    from transformerupscaler_amd import ops, packing
+    a, w, b = rnd((M, K), 18), rnd((N, K), 19, 0.08), rnd((N,), 20, 0.2)
+    wp = packing.pack_linear(w).to(dev)
+    ref = F.linear(bf(a), bf(w), b)
+    close(ops.gemm_tokens(a.to(torch.bfloat16).to(dev), wp, b.to(dev), "bf16"), ref, 1e-2, 1e-2, "gemm bf16")
+    close(ops.gemm_tokens(a.to(torch.bfloat16).to(dev), wp, b.to(dev), "gelu"), F.gelu(ref), 1e-2, 1e-2, "gemm gelu")
+    res = rnd((M, N), 21)
+    got = ops.gemm_tokens(a.to(torch.bfloat16).to(dev), wp, b.to(dev), "res", res=res.to(dev))
+    close(got, ref + res, 2e-4, 1e-4, "gemm res fp32")
+    xs = res.to(dev).clone()        # in-place residual update, as the engine uses it
+    ops.gemm_tokens(a.to(torch.bfloat16).to(dev), wp, b.to(dev), "res", res=xs, out=xs)
+    close(xs, ref + res, 2e-4, 1e-4, "gemm res in place")
+
+
+def test_window_attention(dev, det_sd):
+    from transformerupscaler_amd import ops
+    nwin = 5
+    qkv = bf(rnd((nwin, 64, 576), 22, 1.5))
+    table = det_sd["window_blocks.2.attn.relative_position_bias_table"]
+    idx = O.relative_position_index(8)
+    q, k, v = qkv.view(nwin, 64, 3, 12, 16).permute(2, 0, 3, 1, 4)
+    attn = (q * 0.25) @ k.transpose(-2, -1) + table[idx.view(-1)].view(64, 64, 12).permute(2, 0, 1).unsqueeze(0)
+    ref = (attn.softmax(-1) @ v).transpose(1, 2).reshape(nwin * 64, 192)
+    frag = ops.relpos_bias_expand(table.to(dev))
+    got = ops.window_attn(qkv.view(nwin * 64, 576).to(torch.bfloat16).to(dev), frag)
+    close(got, ref, 1.5e-2, 1e-2, "window attention")
+
+
+@pytest.mark.parametrize("hw", [(20, 28), (68, 84), (64, 64)])
+def test_patch_embed_unembed(dev, hw):
+    from transformerupscaler_amd import ops, packing
+    H, W = hw
+    B = 2
+    feat = bf(rnd((B, 64, H, W), 23))
+    w, b = rnd((192, 64, 8, 8), 24, 0.02), rnd((192,), 25, 0.2)
+    ph, pw = (8 - H % 8) % 8, (8 - W % 8) % 8
+    fp = F.pad(feat, (0, pw, 0, ph), mode="reflect") if (ph or pw) else feat
+    tok = F.conv2d(fp, bf(w), b, stride=8).permute(0, 2, 3, 1)
+    ht, wt = tok.shape[1:3]
+    pb, pr = (8 - ht % 8) % 8, (8 - wt % 8) % 8
+    tokp = F.pad(tok.permute(0, 3, 1, 2), (0, pr, 0, pb)).permute(0, 2, 3, 1).contiguous()
+    ref = O.window_partition(tokp, 8).reshape(-1, 192)
+    nhwc = feat.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    got = ops.patch_embed(nhwc, packing.pack_patch_embed(w).to(dev), b.to(dev))
+    close(got, ref, 2e-3, 1e-3, "patch embed")
+    pad_rows = (ref.abs().sum(1) == 0)
+    assert bool((got.cpu()[pad_rows] == 0).all()), "zero-padded tokens must be exact zeros"
+
+    # unembed: x (window layout, fp32) -> NHWC map + skip
+    xw = rnd(tuple(ref.shape), 26)
+    wu, bu = rnd((192, 64, 8, 8), 27, 0.05), rnd((64,), 28, 0.2)
+    t = O.window_reverse(bf(xw).view(B, -1, 64, 192), 8, ht + pb, wt + pr)[:, :ht, :wt, :].permute(0, 3, 1, 2)
+    refu = (F.conv_transpose2d(t, bf(wu), bu, stride=8)[:, :, :H, :W] + feat).permute(0, 2, 3, 1)
+    gotu = ops.patch_unembed(xw.to(dev), packing.pack_patch_unembed(wu).to(dev), bu.to(dev), nhwc)
+    close(gotu, refu, 2e-2, 1e-2, "patch unembed + skip")

@@ -1,0 +1,69 @@
+"""ctypes binding of libtupscale_hip.so (C ABI in include/tupscale_hip.h).
+
+There is deliberately no fallback: if the library is missing or a symbol is absent the
+import fails loudly, and every call checks the returned hipError_t.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtupscale_hip.so")
+ABI_VERSION = 1
+
+P = c_void_p
+I = c_int
+
+# name -> argtypes, mirrors include/tupscale_hip.h one to one
+SIGNATURES = {
+    "tup_abi_version": [],
+    "tup_conv3x3_c3_fwd": [P, P, P, P, I, I, I, I, P],
+    "tup_conv3x3_c64_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "tup_conv3x3_planar_fwd": [P, P, P, P, P, I, I, I, I, I, P],
+    "tup_resize_aa_fwd": [P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P],
+    "tup_clamp01_fwd": [P, P, c_longlong, P],
+    "tup_layernorm_fwd": [P, P, P, P, P, P, I, P],
+    "tup_relpos_bias_expand": [P, P, P],
+    "tup_window_attn_fwd": [P, P, P, I, P],
+    "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, I, I, I, I, I, P],
+    "tup_patch_embed_fwd": [P, P, P, P, I, I, I, P],
+    "tup_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
+}
+
+
+class TupscaleLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; raise TupscaleLibraryError (never fall back) if unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TupscaleLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C transformerupscaler_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TupscaleLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if lib.tup_abi_version() != ABI_VERSION:
+        raise TupscaleLibraryError(f"ABI mismatch: library {lib.tup_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    err = getattr(load(), name)(*args)
+    if err != 0:
+        raise RuntimeError(f"{name} failed with hipError_t {err}")

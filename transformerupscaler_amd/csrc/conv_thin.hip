@@ -1,0 +1,223 @@
+// Thin (3-channel side) convolutions and the output tail of the FastTransformer path (gfx950).
+//
+//   tup_conv3x3_c3_fwd      conv1 3->64 +bias +ReLU       models/FastTransformer/model.py:202-203,251
+//   tup_conv3x3_planar_fwd  final_upscale 3->3*r*r + PixelShuffle(r)  utils.py:62-63,74-75,83-84 (n_feats=3)
+//                           final_upscale_conv 3->3, fused "+ upscaled_input" and clamp
+//                                                         model.py:212,317,320,327
+//   tup_resize_aa_fwd       antialiased bilinear Resize + clamp   model.py:323-327, train.py:127-130
+//
+// These are HBM-bound: conv1 writes 128 B per pixel and reads 12 B; the planar kernels move a
+// handful of fp32 planes.  conv1 still uses MFMA (im2col K = 27 padded to 32, one K-step) so
+// the VALU never limits the store stream.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int LW = 36;                                  // padded LDS row pitch (elements)
+constexpr int PLANE = HALO_H * LW;                      // 360
+constexpr int ZERO_BASE = 3 * PLANE;                    // a zero plane for the K padding (k >= 27)
+
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    bf16_t* __restrict__ out, int H, int W, int relu, int tilesX, int tilesY)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    int bid = blockIdx.x;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int b = bid / tilesY;
+    const int ty0 = ty * TH, tx0 = tx * TW;
+
+    for (int idx = tid; idx < 4 * PLANE; idx += 256) {
+        const int c = idx / PLANE, rem = idx - c * PLANE;
+        const int yy = rem / LW, xx = rem - yy * LW;
+        const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+        float v = 0.f;
+        if (c < 3 && xx < HALO_W && iy >= 0 && iy < H && ix >= 0 && ix < W)
+            v = x[(((size_t)b * 3 + c) * H + iy) * W + ix];
+        lds[idx] = f32_to_bf16(v);
+    }
+
+    // loop-invariant weight fragments: A[row = cout n_local][k = 8g + j]
+    bf16x8 wf[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) wf[ct] = *reinterpret_cast<const bf16x8*>(wp + (ct * 16 + p) * 32 + 8 * g);
+
+    // im2col offsets of this lane group's 8 k values: k = tap*3 + c
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const int tap = k / 3, c = k - tap * 3;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        koff[j] = (k < 27) ? (c * PLANE + dy * LW + dx) : ZERO_BASE;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+        const int row = 2 * wave + (pg >> 1), x0 = (pg & 1) * 16;
+        const int pb = row * LW + x0 + p;
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = lds[koff[j] + pb];
+        const int oy = ty0 + row, ox = tx0 + x0 + p;
+        f32x4 acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16x16x32(wf[ct], pf, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (oy >= H || ox >= W) continue;
+        bf16_t* o = out + (((size_t)b * H + oy) * W + ox) * 64 + g * 16;
+        uint32_t pk[8];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[ct][e] + bias[g * 16 + ct * 4 + e];
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+            }
+            pk[ct * 2 + 0] = pack_bf16x2(v[0], v[1]);
+            pk[ct * 2 + 1] = pack_bf16x2(v[2], v[3]);
+        }
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    }
+}
+
+// Direct fp32 3x3 conv on planar [B][3][H][W] input, COUT = 3*r*r outputs written through
+// PixelShuffle(r) to [B][3][H*r][W*r]; optional "+ add" (same shape as out) and clamp to [0,1].
+// weights: [COUT][28] fp32 (27 taps in (cin, ky, kx) order + 1 pad), bias [COUT].
+__global__ __launch_bounds__(256) void conv3x3_planar_kernel(
+    const float* __restrict__ x, const float* __restrict__ w28, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ out, int H, int W, int r, int clamp01)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [COUT][28] + [COUT]
+    const int cout = 3 * r * r;
+    for (int i = threadIdx.x; i < cout * 28; i += 256) wl[i] = w28[i];
+    for (int i = threadIdx.x; i < cout; i += 256) wl[cout * 28 + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    float in[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iy = oy + dy - 1, ix = ox + dx - 1;
+                in[c * 9 + dy * 3 + dx] = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                              ? x[(((size_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
+            }
+    const int Hr = H * r, Wr = W * r, rr = r * r;
+    for (int co = 0; co < cout; ++co) {
+        const f32x4* wv = reinterpret_cast<const f32x4*>(wl + co * 28);
+        float s = wl[cout * 28 + co];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const f32x4 wq = wv[q];
+            s = fmaf(wq[0], in[q * 4 + 0], s);
+            s = fmaf(wq[1], in[q * 4 + 1], s);
+            s = fmaf(wq[2], in[q * 4 + 2], s);
+            if (q < 6) s = fmaf(wq[3], in[q * 4 + 3], s);
+        }
+        const int c = co / rr, sp = co - c * rr;
+        const int si = sp / r, sj = sp - si * r;
+        const size_t oi = (((size_t)b * 3 + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj);
+        if (add) s += add[oi];
+        if (clamp01) s = fminf(fmaxf(s, 0.f), 1.f);
+        out[oi] = s;
+    }
+}
+
+// Separable antialiased-bilinear resize evaluated as one 2-D gather per output pixel.
+// Tap tables (ymin/ysize/yw[Ho][KY], xmin/xsize/xw[Wo][KX]) are built on the host exactly as
+// aten's _compute_indices_weights_aa does (float32); see transformerupscaler_amd/resize_taps.py.
+__global__ __launch_bounds__(256) void resize_aa_kernel(
+    const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ ymin,
+    const int* __restrict__ ysize, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
+    const int* __restrict__ xsize, const float* __restrict__ xw, int KX, int Hi, int Wi, int Ho, int Wo,
+    int clamp01)
+{
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane = blockIdx.z;
+    if (ox >= Wo || oy >= Ho) return;
+    const float* src = in + (size_t)plane * Hi * Wi;
+    const int y0 = ymin[oy], ny = ysize[oy], x0 = xmin[ox], nx = xsize[ox];
+    float acc = 0.f;
+    for (int i = 0; i < ny; ++i) {
+        const float* rowp = src + (size_t)(y0 + i) * Wi + x0;
+        float h = 0.f;
+        for (int j = 0; j < nx; ++j) h = fmaf(xw[ox * KX + j], rowp[j], h);
+        acc = fmaf(yw[oy * KY + i], h, acc);
+    }
+    if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+    out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
+}
+
+__global__ __launch_bounds__(256) void clamp01_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) out[i] = fminf(fmaxf(in[i], 0.f), 1.f);
+}
+
+}  // namespace
+
+// x: [B][3][H][W] fp32 (NCHW, as the reference module receives it); wp: [64][32] bf16 packed
+// (row n_local = ct*16+4g+e holds channel g*16+ct*4+e; k = tap*3 + cin, zero padded 27..31);
+// bias: [64] fp32 in channel order; out: [B][H][W][64] bf16.
+extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* bias, void* out,
+                                  int B, int H, int W, int relu, void* stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long nblk = (long long)tilesX * tilesY * B;
+    if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    conv3x3_c3_kernel<<<dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        x, (const bf16_t*)wp, bias, (bf16_t*)out, H, W, relu, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tup_conv3x3_planar_fwd(const float* x, const float* w28, const float* bias, const float* add,
+                                      float* out, int B, int H, int W, int r, int clamp01, void* stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (r < 1 || r > 6 || B > 65535) return (int)hipErrorInvalidValue;
+    const int cout = 3 * r * r;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    conv3x3_planar_kernel<<<grid, dim3(256), (size_t)cout * 29 * sizeof(float),
+                            reinterpret_cast<hipStream_t>(stream)>>>(x, w28, bias, add, out, H, W, r, clamp01);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, const int* ysize, const float* yw,
+                                 int KY, const int* xmin, const int* xsize, const float* xw, int KX, int planes,
+                                 int Hi, int Wi, int Ho, int Wo, int clamp01, void* stream)
+{
+    if (planes <= 0) return 0;
+    if (planes > 65535) return (int)hipErrorInvalidValue;
+    dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, planes);
+    resize_aa_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tup_clamp01_fwd(const float* in, float* out, long long n, void* stream)
+{
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    clamp01_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(in, out, (size_t)n);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,293 @@
+// Token-side GEMMs of the FastTransformer path on MFMA (gfx950), with gather / scatter
+// addressing and fused epilogues.  out[m][n] = epi( sum_k A[m][k] * Wt[n][k] + bias[n] ).
+//
+// Reference call sites replaced (aten linear / conv2d k8s8 / conv_transpose2d k8s8):
+//   qkv, proj            models/FastTransformer/model.py:79,81,115,131
+//   mlp.0 (+erf GELU), mlp.2   model.py:146-151,170
+//   residual adds        model.py:164,171
+//   patch_embed + NCHW->NHWC + zero token pad + window_partition   model.py:31-45,215,268-285
+//   window_reverse + crop + patch_unembed + crop + skip add        model.py:47-63,225,292-309
+//
+// One workgroup = 4 waves = 128 token rows x 64 output features, K streamed in 64-wide
+// chunks through double-buffered, XOR-swizzled LDS.  MFMA A operand = weight rows, B operand =
+// token rows, so each lane finishes with 16 consecutive output features of one token.
+// Weight rows are pre-permuted on the host inside every 64-row group (row ct*16+4g+e holds
+// feature g*16+ct*4+e) to make that true.
+#include "common.h"
+
+namespace {
+
+enum { A_BF16 = 0, A_F32 = 1, A_PATCH = 2 };
+enum { E_BF16 = 0, E_GELU_BF16 = 1, E_RES_F32 = 2, E_PATCH_EMBED = 3, E_UNEMBED = 4 };
+
+struct GemmParams {
+    const void* A; int lda;
+    const bf16_t* Wt;            // [N][K] bf16, rows permuted per 64-group
+    const float* bias;           // [N] natural order (E_UNEMBED: [64])
+    void* out; int ldo;
+    const float* res;            // E_RES_F32: [M][ldo] fp32
+    const bf16_t* skip;          // E_UNEMBED: NHWC feat to add
+    int M, N, K;
+    int H, W, Ht, Wt_, nWx, nWy; // geometry for the patch modes (token rows are in window layout)
+};
+
+constexpr int BM = 128, BN = 64, BK = 64;
+constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;
+
+struct TokPos { int b, ty, tx; bool valid; };
+
+TUP_DEVICE TokPos token_of_row(int m, const GemmParams& p) {
+    TokPos t;
+    const int tok = m & 63;
+    int win = m >> 6;
+    const int wx = win % p.nWx; win /= p.nWx;
+    const int wy = win % p.nWy;
+    t.b = win / p.nWy;
+    t.ty = wy * 8 + (tok >> 3);
+    t.tx = wx * 8 + (tok & 7);
+    t.valid = (t.ty < p.Ht) && (t.tx < p.Wt_);
+    return t;
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_lds = smem;                       // 2 x A_STAGE
+    char* w_lds = smem + 2 * A_STAGE;         // 2 x W_STAGE
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int nk = p.K / BK;
+
+    // ---- per-thread A row bookkeeping: thread loads chunk (tid&7) of rows (tid>>3) + 32u ----
+    const int achunk = tid & 7;
+    const char* arow[4];
+    bool avalid[4];
+    int apy[4], apx[4], abat[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int m = m0 + (tid >> 3) + 32 * u;
+        avalid[u] = m < p.M;
+        if (m >= p.M) m = p.M - 1;
+        if constexpr (AMODE == A_BF16) arow[u] = (const char*)p.A + (size_t)m * p.lda * 2;
+        else if constexpr (AMODE == A_F32) arow[u] = (const char*)p.A + (size_t)m * p.lda * 4;
+        else {
+            const TokPos t = token_of_row(m, p);
+            avalid[u] = avalid[u] && t.valid;
+            apy[u] = t.ty * 8; apx[u] = t.tx * 8; abat[u] = t.b;
+            arow[u] = nullptr;
+        }
+    }
+
+    u32x4 areg[(AMODE == A_F32) ? 8 : 4];
+    u32x4 wreg[2];
+
+    auto load_stage = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (AMODE == A_BF16) {
+                areg[u] = avalid[u] ? *reinterpret_cast<const u32x4*>(arow[u] + (size_t)(kc * BK + achunk * 8) * 2)
+                                    : u32x4{0u, 0u, 0u, 0u};
+            } else if constexpr (AMODE == A_F32) {
+                const char* s = arow[u] + (size_t)(kc * BK + achunk * 8) * 4;
+                areg[2 * u] = avalid[u] ? *reinterpret_cast<const u32x4*>(s) : u32x4{0u, 0u, 0u, 0u};
+                areg[2 * u + 1] = avalid[u] ? *reinterpret_cast<const u32x4*>(s + 16) : u32x4{0u, 0u, 0u, 0u};
+            } else {
+                // k chunk kc = patch pixel (i, j); reflect-pad rows/cols beyond the map (model.py:256-261)
+                const int i = kc >> 3, j = kc & 7;
+                int py = apy[u] + i, px = apx[u] + j;
+                if (py >= p.H) py = 2 * p.H - 2 - py;
+                if (px >= p.W) px = 2 * p.W - 2 - px;
+                const bf16_t* s = (const bf16_t*)p.A + (((size_t)abat[u] * p.H + py) * p.W + px) * 64 + achunk * 8;
+                areg[u] = avalid[u] ? *reinterpret_cast<const u32x4*>(s) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 256, row = idx >> 3, c = idx & 7;
+            wreg[u] = *reinterpret_cast<const u32x4*>(p.Wt + (size_t)(n0 + row) * p.K + kc * BK + c * 8);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = (tid >> 3) + 32 * u;
+            u32x4 v;
+            if constexpr (AMODE == A_F32) {
+                const f32x4 lo = __builtin_bit_cast(f32x4, areg[2 * u]);
+                const f32x4 hi = __builtin_bit_cast(f32x4, areg[2 * u + 1]);
+                v = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]),
+                          pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+            } else {
+                v = areg[u];
+            }
+            *reinterpret_cast<u32x4*>(a_lds + buf * A_STAGE + swz128(row, achunk)) = v;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 256;
+            *reinterpret_cast<u32x4*>(w_lds + buf * W_STAGE + swz128(idx >> 3, idx & 7)) = wreg[u];
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_stage(kc + 1);
+        const char* ab = a_lds + buf * A_STAGE;
+        const char* wb = w_lds + buf * W_STAGE;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int chunk = kh * 4 + g;
+            bf16x8 tf[2], wf[4];
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+                tf[tg] = *reinterpret_cast<const bf16x8*>(ab + swz128(32 * wave + 16 * tg + pl, chunk));
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+                wf[ct] = *reinterpret_cast<const bf16x8*>(wb + swz128(ct * 16 + pl, chunk));
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = mfma16x16x32(wf[ct], tf[tg], acc[tg][ct]);
+        }
+        if (kc + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds features n0 + g*16 + ct*4 + e of token row m ----
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg) {
+        const int m = m0 + 32 * wave + 16 * tg + pl;
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ct][e];
+        const int nb = n0 + g * 16;
+
+        if constexpr (EPI == E_BF16 || EPI == E_GELU_BF16) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float a = v[2 * q] + p.bias[nb + 2 * q], b = v[2 * q + 1] + p.bias[nb + 2 * q + 1];
+                if constexpr (EPI == E_GELU_BF16) { a = gelu_erf(a); b = gelu_erf(b); }
+                pk[q] = pack_bf16x2(a, b);
+            }
+            bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
+            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        } else if constexpr (EPI == E_RES_F32) {
+            float* o = (float*)p.out + (size_t)m * p.ldo + nb;
+            const float* rs = p.res + (size_t)m * p.ldo + nb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + 4 * q);
+                f32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = v[4 * q + e] + p.bias[nb + 4 * q + e] + rv[e];
+                *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
+            }
+        } else if constexpr (EPI == E_PATCH_EMBED) {
+            // zero-padded tokens are exact zeros (no bias): model.py:273-280
+            const TokPos t = token_of_row(m, p);
+            float* o = (float*)p.out + (size_t)m * p.ldo + nb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + p.bias[nb + 4 * q + e] : 0.f;
+                *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
+            }
+        } else {  // E_UNEMBED: n tile = patch pixel (i, j); features = base channel o
+            const TokPos t = token_of_row(m, p);
+            const int pix = n0 >> 6, i = pix >> 3, j = pix & 7;
+            const int py = t.ty * 8 + i, px = t.tx * 8 + j;
+            if (!t.valid || py >= p.H || px >= p.W) continue;
+            const size_t off = (((size_t)t.b * p.H + py) * p.W + px) * 64 + g * 16;
+            const u32x4 s0 = *reinterpret_cast<const u32x4*>(p.skip + off);
+            const u32x4 s1 = *reinterpret_cast<const u32x4*>(p.skip + off + 8);
+            uint32_t pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t sw = (q < 4) ? s0[q & 3] : s1[q & 3];
+                const float sa = __builtin_bit_cast(float, sw << 16);
+                const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
+                pk[q] = pack_bf16x2(v[2 * q] + p.bias[g * 16 + 2 * q] + sa, v[2 * q + 1] + p.bias[g * 16 + 2 * q + 1] + sb);
+            }
+            bf16_t* o = (bf16_t*)p.out + off;
+            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        }
+    }
+}
+
+template <int AMODE, int EPI>
+int launch(const GemmParams& p, hipStream_t s)
+{
+    if (p.M <= 0) return 0;
+    if (p.N % BN != 0 || p.K % BK != 0) return (int)hipErrorInvalidValue;
+    const int mt = (p.M + BM - 1) / BM;
+    if (mt > 65535) return (int)hipErrorInvalidValue;
+    gemm_tokens_kernel<AMODE, EPI><<<dim3(p.N / BN, mt), dim3(256), 2 * (A_STAGE + W_STAGE), s>>>(p);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// epilogue: 0 = +bias -> bf16, 1 = +bias, erf-GELU -> bf16, 2 = +bias +res(fp32) -> fp32.
+// a_dtype: 0 = bf16 A, 1 = fp32 A (converted to bf16 on the way into LDS).
+extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
+                                   const float* res, void* out, int ldo, int M, int N, int K, int epilogue,
+                                   void* stream)
+{
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.ldo = ldo; p.res = res;
+    p.M = M; p.N = N; p.K = K;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (a_dtype == 0 && epilogue == 0) return launch<A_BF16, E_BF16>(p, s);
+    if (a_dtype == 0 && epilogue == 1) return launch<A_BF16, E_GELU_BF16>(p, s);
+    if (a_dtype == 0 && epilogue == 2) return launch<A_BF16, E_RES_F32>(p, s);
+    if (a_dtype == 1 && epilogue == 0) return launch<A_F32, E_BF16>(p, s);
+    return (int)hipErrorInvalidValue;
+}
+
+// feat: [B][H][W][64] bf16.  Wt: [192][4096] bf16, k = (i*8+j)*64 + c.  x_out: fp32 [B*nWy*nWx*64][192]
+// in window layout (zero rows for padded tokens).
+extern "C" int tup_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, float* x_out,
+                                   int B, int H, int W, void* stream)
+{
+    GemmParams p{};
+    p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
+    p.A = feat; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = x_out; p.ldo = 192;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 192; p.K = 4096;
+    // reflect padding needs pad < dim (same constraint as F.pad(mode='reflect'))
+    if ((p.Ht * 8 - H) >= H || (p.Wt_ * 8 - W) >= W) return (int)hipErrorInvalidValue;
+    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// x: fp32 [B*nWy*nWx*64][192] window layout.  Wt: [4096][192] bf16, n = (i*8+j)*64 + o (rows permuted
+// per 64-group).  bias: [64].  skip / out: [B][H][W][64] bf16 NHWC; out = skip + unembed(x) + bias.
+extern "C" int tup_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip,
+                                     void* out, int B, int H, int W, void* stream)
+{
+    GemmParams p{};
+    p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
+    p.A = x; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
+    return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,101 @@
+"""Forward orchestration of the FastTransformer path over the HIP kernels.
+
+Mirrors TransformerModel.forward (reference models/FastTransformer/model.py:231-327) stage by
+stage; every stage is one C-ABI launch (ops.py).  Activations: NHWC bf16 for the 64-channel
+maps, fp32 planar for the 3-channel images, fp32 residual stream for the tokens.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+from .weights import BLOCKS, VALID_SCALES, upsampler_layout
+
+
+# Optional per-stage timing hook (bench.py installs one): callable(name) -> context manager.
+stage_timer = None
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _stage(name: str):
+    return stage_timer(name) if stage_timer is not None else _NullCtx()
+
+
+def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
+    """model.py:245-248 + the ValueError of utils.py:96-97."""
+    if upscale_factor is not None:
+        res_out = (h * upscale_factor, w * upscale_factor)
+    else:
+        upscale_factor = math.ceil(max(res_out[0] / h, res_out[1] / w))
+    if upscale_factor not in VALID_SCALES:
+        raise ValueError(f"Requested scale={upscale_factor} was not built.")
+    return (int(res_out[0]), int(res_out[1])), int(upscale_factor)
+
+
+def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
+    """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
+    for i in range(BLOCKS):
+        y = ops.layernorm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"])
+        qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
+        att = ops.window_attn(qkv, bias_frags[i])
+        ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=x, out=x)
+        y = ops.layernorm(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"])
+        hid = ops.gemm_tokens(y, pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"], "gelu")
+        ops.gemm_tokens(hid, pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"], "res", res=x, out=x)
+        if capture is not None:
+            capture[f"block{i}"] = x.clone()
+            capture[f"block{i}_qkv"] = qkv
+            capture[f"block{i}_attn_out"] = att
+    return x
+
+
+def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int, res_out: Tuple[int, int],
+            require_ratio: bool = True, capture: Optional[dict] = None) -> torch.Tensor:
+    cap = capture
+    x = x.contiguous().float()
+    B, _, H, W = x.shape
+    feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
+    feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+    del feat1
+    # branch A: Upsampler + up1_conv (conv, no bias, ReLU)
+    up = feat
+    for si, (_, r) in enumerate(upsampler_layout(scale)):
+        with _stage(f"up1.{si}"):
+            up = ops.conv_c64(up, pk[f"up1.{si}.w"], pk[f"up1.{si}.b"], r, relu=False)
+    upscaled_input = ops.conv_c64_thin(up, pk["up1_conv.w"], None, 3, relu=True)
+    if cap is not None:
+        cap["feat"] = feat; cap["up1"] = up; cap["upscaled_input"] = upscaled_input
+    del up
+    # branch B: tokens
+    xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])
+    if cap is not None:
+        cap["win_in"] = xw.clone()
+    xw = transformer_blocks(pk, xw, bias_frags, cap)
+    combined = ops.patch_unembed(xw, pk["pu.w"], pk["pu.b"], feat)
+    dec = ops.conv_c64(combined, pk["dec1.w"], pk["dec1.b"], 1, relu=True)
+    residual = ops.conv_c64_thin(dec, pk["dec2.w"], pk["dec2.b"], 3, relu=False)
+    if cap is not None:
+        cap["combined"] = combined; cap["dec"] = dec; cap["residual"] = residual
+    t = residual
+    for si, (_, r) in enumerate(upsampler_layout(scale)):
+        t = ops.conv_planar(t, pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r)
+    hs, ws = H * scale, W * scale
+    # model.py:323: `res_out != (out.shape[2], out.shape[2])` -- the (H, H) quirk is kept; Resize to an
+    # identical size is the identity.
+    needs_resize = bool(require_ratio) and tuple(res_out) != (hs, hs) and tuple(res_out) != (hs, ws)
+    out = ops.conv_planar(t, pk["fuc.w"], pk["fuc.b"], 1, add=upscaled_input, clamp=not needs_resize)
+    if cap is not None:
+        cap["sum"] = out
+    if needs_resize:
+        out = ops.resize_aa(out, res_out, clamp=True)
+    return out

@@ -1,0 +1,181 @@
+"""Tensor-level wrappers over the C ABI (include/tupscale_hip.h).
+
+Each wrapper validates device / dtype / shape / contiguity on the host (a kernel that faults
+can take the whole GPU node down), allocates the output with torch (plumbing only) and launches
+on the caller's current HIP stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .resize_taps import aa_taps
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, shape=None, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def _opt(t, dtype, shape, name):
+    return None if t is None else _chk(t, dtype, shape, name)
+
+
+def conv1(x, wp, bias, relu=True):
+    B, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty((B, H, W, 64), dtype=BF16, device=x.device)
+    _lib.call("tup_conv3x3_c3_fwd", _chk(x, F32, None, "x"), _chk(wp, BF16, (64, 32), "wp"),
+              _chk(bias, F32, (64,), "bias"), out.data_ptr(), B, H, W, int(relu), _stream())
+    return out
+
+
+def conv_c64(x, wp, bias, r=1, relu=False):
+    """NHWC bf16 conv 64 -> 64*r*r with fused PixelShuffle(r); returns [B][H*r][W*r][64] bf16."""
+    B, H, W, C = x.shape
+    assert C == 64
+    nt = r * r
+    out = torch.empty((B, H * r, W * r, 64), dtype=BF16, device=x.device)
+    _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (nt, 9, 64, 64), "wp"),
+              _opt(bias, F32, (nt, 64), "bias"), out.data_ptr(), B, H, W, nt, r, 64, int(relu), 0, _stream())
+    return out
+
+
+def conv_c64_thin(x, wp, bias, cout, relu=False):
+    """NHWC bf16 conv 64 -> cout (<=16); returns fp32 planar [B][cout][H][W]."""
+    B, H, W, C = x.shape
+    assert C == 64 and 1 <= cout <= 16
+    out = torch.empty((B, cout, H, W), dtype=F32, device=x.device)
+    _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (1, 9, 16, 64), "wp"),
+              _opt(bias, F32, (cout,), "bias"), out.data_ptr(), B, H, W, 1, 1, cout, int(relu), 1, _stream())
+    return out
+
+
+def conv_planar(x, w28, bias, r=1, add=None, clamp=False):
+    B, C, H, W = x.shape
+    assert C == 3
+    cout = 3 * r * r
+    out = torch.empty((B, 3, H * r, W * r), dtype=F32, device=x.device)
+    _lib.call("tup_conv3x3_planar_fwd", _chk(x, F32, None, "x"), _chk(w28, F32, (cout, 28), "w28"),
+              _opt(bias, F32, (cout,), "bias"), _opt(add, F32, out.shape, "add"), out.data_ptr(),
+              B, H, W, r, int(clamp), _stream())
+    return out
+
+
+_TAP_CACHE = {}
+
+
+def _taps_on(device, in_size, out_size):
+    key = (str(device), in_size, out_size)
+    if key not in _TAP_CACHE:
+        lo, n, w, k = aa_taps(in_size, out_size)
+        _TAP_CACHE[key] = (torch.from_numpy(lo).to(device), torch.from_numpy(n).to(device),
+                           torch.from_numpy(w).to(device), k)
+    return _TAP_CACHE[key]
+
+
+def resize_aa(x, size, clamp=False):
+    B, C, Hi, Wi = x.shape
+    Ho, Wo = size
+    ylo, yn, yw, ky = _taps_on(x.device, Hi, Ho)
+    xlo, xn, xw, kx = _taps_on(x.device, Wi, Wo)
+    out = torch.empty((B, C, Ho, Wo), dtype=F32, device=x.device)
+    _lib.call("tup_resize_aa_fwd", _chk(x, F32, None, "x"), out.data_ptr(), ylo.data_ptr(), yn.data_ptr(),
+              yw.data_ptr(), ky, xlo.data_ptr(), xn.data_ptr(), xw.data_ptr(), kx, B * C, Hi, Wi, Ho, Wo,
+              int(clamp), _stream())
+    return out
+
+
+def clamp01(x):
+    out = torch.empty_like(x)
+    _lib.call("tup_clamp01_fwd", _chk(x, F32, None, "x"), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def layernorm(x, gamma, beta, save_stats=False):
+    M, D = x.shape
+    assert D == 192
+    y = torch.empty((M, 192), dtype=BF16, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty((M,), dtype=F32, device=x.device)
+        rstd = torch.empty((M,), dtype=F32, device=x.device)
+    _lib.call("tup_layernorm_fwd", _chk(x, F32, None, "x"), _chk(gamma, F32, (192,), "gamma"),
+              _chk(beta, F32, (192,), "beta"), y.data_ptr(), None if mean is None else mean.data_ptr(),
+              None if rstd is None else rstd.data_ptr(), M, _stream())
+    return (y, mean, rstd) if save_stats else y
+
+
+def relpos_bias_expand(table):
+    frag = torch.empty((12, 4, 4, 64, 4), dtype=F32, device=table.device)
+    _lib.call("tup_relpos_bias_expand", _chk(table, F32, (225, 12), "table"), frag.data_ptr(), _stream())
+    return frag
+
+
+def window_attn(qkv, bias_frag):
+    M, D = qkv.shape
+    assert D == 576 and M % 64 == 0
+    out = torch.empty((M, 192), dtype=BF16, device=qkv.device)
+    _lib.call("tup_window_attn_fwd", _chk(qkv, BF16, None, "qkv"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
+              out.data_ptr(), M // 64, _stream())
+    return out
+
+
+def gemm_tokens(a, wt, bias, epilogue, res=None, out=None):
+    """epilogue 'bf16' | 'gelu' | 'res' (fp32 out = a@wt^T + bias + res)."""
+    M, K = a.shape
+    N = wt.shape[0]
+    assert tuple(wt.shape) == (N, K) and N % 64 == 0 and K % 64 == 0
+    a_dtype = {BF16: 0, F32: 1}[a.dtype]
+    epi = {"bf16": 0, "gelu": 1, "res": 2}[epilogue]
+    if epi == 2:
+        if out is None:
+            out = torch.empty((M, N), dtype=F32, device=a.device)
+        _chk(out, F32, (M, N), "out")
+        resp = _chk(res, F32, (M, N), "res")
+    else:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+        resp = None
+    _lib.call("tup_gemm_tokens_fwd", _chk(a, a.dtype, None, "a"), a_dtype, K, _chk(wt, BF16, None, "wt"),
+              _chk(bias, F32, (N,), "bias"), resp, out.data_ptr(), N, M, N, K, epi, _stream())
+    return out
+
+
+def window_geometry(H, W):
+    ht, wt = (H + 7) // 8, (W + 7) // 8
+    nwy, nwx = (ht + 7) // 8, (wt + 7) // 8
+    return ht, wt, nwy, nwx
+
+
+def patch_embed(feat, wt, bias):
+    B, H, W, C = feat.shape
+    assert C == 64
+    if (8 - H % 8) % 8 >= H or (8 - W % 8) % 8 >= W:
+        raise RuntimeError("reflect padding needs pad < dim")     # same rule as F.pad(mode='reflect')
+    _, _, nwy, nwx = window_geometry(H, W)
+    x = torch.empty((B * nwy * nwx * 64, 192), dtype=F32, device=feat.device)
+    _lib.call("tup_patch_embed_fwd", _chk(feat, BF16, None, "feat"), _chk(wt, BF16, (192, 4096), "wt"),
+              _chk(bias, F32, (192,), "bias"), x.data_ptr(), B, H, W, _stream())
+    return x
+
+
+def patch_unembed(x, wt, bias, skip):
+    B, H, W, C = skip.shape
+    _, _, nwy, nwx = window_geometry(H, W)
+    out = torch.empty_like(skip)
+    _lib.call("tup_patch_unembed_fwd", _chk(x, F32, (B * nwy * nwx * 64, 192), "x"), _chk(wt, BF16, (4096, 192), "wt"),
+              _chk(bias, F32, (64,), "bias"), _chk(skip, BF16, None, "skip"), out.data_ptr(), B, H, W, _stream())
+    return out

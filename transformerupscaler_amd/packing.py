@@ -1,0 +1,103 @@
+"""Host-side weight packing into the layouts the HIP kernels consume (include/tupscale_hip.h).
+
+Pure index shuffles + bf16 casts with torch ops on whatever device the parameters live on
+(plumbing; a few MB per call).  The reference state_dict layout is the source of truth.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from .weights import BLOCKS, upsampler_layout
+
+# row n_local = ct*16 + 4g + e of every 64-row weight group holds output feature g*16 + ct*4 + e,
+# so that an MFMA lane (group g) ends up with 16 consecutive features (see csrc/common.h).
+_PERM64 = torch.tensor([((n >> 2) & 3) * 16 + (n >> 4) * 4 + (n & 3) for n in range(64)], dtype=torch.long)
+
+
+def perm_rows64(w: torch.Tensor) -> torch.Tensor:
+    n = w.shape[0]
+    assert n % 64 == 0
+    idx = (torch.arange(n // 64).view(-1, 1) * 64 + _PERM64.view(1, -1)).reshape(-1).to(w.device)
+    return w.index_select(0, idx)
+
+
+def pack_conv_c64(weight: torch.Tensor, bias, r: int):
+    """Conv2d(64, 64*r*r, 3) (+PixelShuffle r) -> bf16 [r*r][9][64][64], bias fp32 [r*r][64]."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    assert cin == 64 and cout == 64 * r * r and weight.shape[2:] == (3, 3)
+    w = weight.reshape(64, r * r, 64, 9)                 # [c][sp][cin][tap]  (cout = c*r*r + sp)
+    w = w.permute(1, 3, 0, 2)                            # [sp][tap][c][cin]
+    w = w.index_select(2, _PERM64.to(w.device))          # row n_local <- channel perm[n_local]
+    b = None if bias is None else bias.reshape(64, r * r).t().contiguous().float()
+    return w.contiguous().to(torch.bfloat16), b
+
+
+def pack_conv_c64_thin(weight: torch.Tensor):
+    """Conv2d(64, co<=16, 3) -> bf16 [1][9][16][64] (rows >= co zero)."""
+    co = weight.shape[0]
+    assert weight.shape[1] == 64 and co <= 16
+    w = torch.zeros(9, 16, 64, dtype=weight.dtype, device=weight.device)
+    w[:, :co, :] = weight.reshape(co, 64, 9).permute(2, 0, 1)
+    return w.unsqueeze(0).contiguous().to(torch.bfloat16)
+
+
+def pack_conv1(weight: torch.Tensor):
+    """Conv2d(3, 64, 3) -> bf16 [64][32], k = tap*3 + cin, rows permuted."""
+    assert tuple(weight.shape) == (64, 3, 3, 3)
+    w = torch.zeros(64, 32, dtype=weight.dtype, device=weight.device)
+    w[:, :27] = weight.permute(0, 2, 3, 1).reshape(64, 27)
+    return perm_rows64(w).contiguous().to(torch.bfloat16)
+
+
+def pack_planar(weight: torch.Tensor):
+    """Conv2d(3, cout, 3) -> fp32 [cout][28] ((cin, ky, kx) order + one pad)."""
+    cout = weight.shape[0]
+    assert weight.shape[1:] == (3, 3, 3)
+    w = torch.zeros(cout, 28, dtype=torch.float32, device=weight.device)
+    w[:, :27] = weight.reshape(cout, 27).float()
+    return w.contiguous()
+
+
+def pack_linear(weight: torch.Tensor):
+    """nn.Linear weight [N][K] -> bf16 with rows permuted per 64-group."""
+    return perm_rows64(weight).contiguous().to(torch.bfloat16)
+
+
+def pack_patch_embed(weight: torch.Tensor):
+    """Conv2d(64,192,k8,s8) weight [192][64][8][8] -> bf16 [192][4096], k = (i*8+j)*64 + c."""
+    return pack_linear(weight.permute(0, 2, 3, 1).reshape(192, 4096))
+
+
+def pack_patch_unembed(weight: torch.Tensor):
+    """ConvTranspose2d(192,64,k8,s8) weight [192][64][8][8] -> bf16 [4096][192], n = (i*8+j)*64 + o."""
+    return pack_linear(weight.permute(2, 3, 1, 0).reshape(4096, 192))
+
+
+def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int) -> Dict[str, torch.Tensor]:
+    """Everything one forward at `scale` needs, keyed by short names."""
+    pk: Dict[str, torch.Tensor] = {}
+    f32 = lambda t: t.detach().float().contiguous()
+    pk["conv1.w"] = pack_conv1(sd["conv1.weight"].detach()); pk["conv1.b"] = f32(sd["conv1.bias"])
+    pk["conv2.w"], pk["conv2.b"] = pack_conv_c64(sd["conv2.weight"].detach(), sd["conv2.bias"].detach(), 1)
+    for si, (idx, r) in enumerate(upsampler_layout(scale)):
+        k = f"up1.upsamplers.{scale}.{idx}"
+        pk[f"up1.{si}.w"], pk[f"up1.{si}.b"] = pack_conv_c64(sd[k + ".weight"].detach(), sd[k + ".bias"].detach(), r)
+        k = f"final_upscale.upsamplers.{scale}.{idx}"
+        pk[f"fu.{si}.w"] = pack_planar(sd[k + ".weight"].detach()); pk[f"fu.{si}.b"] = f32(sd[k + ".bias"])
+    pk["up1_conv.w"] = pack_conv_c64_thin(sd["up1_conv.conv.weight"].detach())
+    pk["fuc.w"] = pack_planar(sd["final_upscale_conv.weight"].detach()); pk["fuc.b"] = f32(sd["final_upscale_conv.bias"])
+    pk["pe.w"] = pack_patch_embed(sd["patch_embed.weight"].detach()); pk["pe.b"] = f32(sd["patch_embed.bias"])
+    for i in range(BLOCKS):
+        p = f"window_blocks.{i}"
+        for nm in ("norm1", "norm2"):
+            pk[f"b{i}.{nm}.w"] = f32(sd[f"{p}.{nm}.weight"]); pk[f"b{i}.{nm}.b"] = f32(sd[f"{p}.{nm}.bias"])
+        pk[f"b{i}.table"] = f32(sd[f"{p}.attn.relative_position_bias_table"])
+        for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
+            pk[f"b{i}.{nm}.w"] = pack_linear(sd[f"{p}.{key}.weight"].detach())
+            pk[f"b{i}.{nm}.b"] = f32(sd[f"{p}.{key}.bias"])
+    pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
+    pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
+    pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])
+    return pk

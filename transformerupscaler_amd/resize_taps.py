@@ -1,0 +1,36 @@
+"""Tap tables of the antialiased bilinear resize (torchvision.transforms.Resize on tensors).
+
+Product-side builder for tup_resize_aa_fwd.  Follows aten's float32 evaluation
+(_compute_indices_weights_aa in UpSampleKernel.cpp, PyTorch being a third-party dependency of
+the reference: requirements.txt:42) so results agree with the reference's CPU path to rounding.
+Vectorised numpy, float32 throughout.
+"""
+from __future__ import annotations
+
+import functools
+import math
+
+import numpy as np
+
+
+@functools.lru_cache(maxsize=64)
+def aa_taps(in_size: int, out_size: int):
+    f = np.float32
+    scale = f(in_size) / f(out_size)
+    support = scale if scale >= 1.0 else f(1.0)
+    invscale = f(1.0) / scale if scale >= 1.0 else f(1.0)
+    kmax = int(math.ceil(float(support))) * 2 + 1
+    i = np.arange(out_size, dtype=np.float32)
+    center = (scale * (i + f(0.5))).astype(np.float32)
+    lo = np.maximum(0, (center - support + f(0.5)).astype(np.float32).astype(np.int64))
+    hi = np.minimum(in_size, (center + support + f(0.5)).astype(np.float32).astype(np.int64))
+    n = (hi - lo).astype(np.int32)
+    j = np.arange(kmax, dtype=np.int64)[None, :]
+    arg = ((j + lo[:, None]).astype(np.float32) - center[:, None] + f(0.5)).astype(np.float32) * invscale
+    w = np.maximum(f(0.0), f(1.0) - np.abs(arg)).astype(np.float32)
+    w = np.where(j < n[:, None], w, f(0.0)).astype(np.float32)
+    tot = np.zeros(out_size, np.float32)
+    for k in range(kmax):           # sequential float32 accumulation, as aten does
+        tot = (tot + w[:, k]).astype(np.float32)
+    w = np.where(tot[:, None] != 0, w / np.where(tot == 0, f(1.0), tot)[:, None], w).astype(np.float32)
+    return lo.astype(np.int32), n, np.ascontiguousarray(w), kmax

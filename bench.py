@@ -37,6 +37,7 @@ def cpu_baseline(batch_images: int):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("TUP_CPU_THREADS", "16")))     # the 1-GPU box's CPU share is 16
     torch.set_num_threads(cores)
     sd = deterministic_state_dict(0)
     x = torch.rand((1, 3, LR_H, LR_W), generator=torch.Generator().manual_seed(1234))

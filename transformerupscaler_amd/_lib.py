@@ -49,6 +49,10 @@ def load():
         raise TupscaleLibraryError(
             f"{LIB_PATH} not found: build it with `make -C transformerupscaler_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # The kernels must run in the same HIP runtime instance as the device memory and streams they are
+    # handed.  torch bundles its own libamdhip64; importing it first makes the dynamic loader resolve our
+    # DT_NEEDED libamdhip64.so.N to that already-loaded copy instead of a second runtime from /opt/rocm.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         try:

@@ -1,0 +1,123 @@
+"""CPU-side boundary checks: the C-ABI library loads and exports every symbol include/tupscale_hip.h
+declares (no compute without a GPU), the plugin module keeps the reference's surface, and the host
+packing logic produces the layouts the kernels assume (emulated with torch on the CPU)."""
+import importlib
+import inspect
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from transformerupscaler_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "tupscale_hip.h")).read()
+    declared = set(re.findall(r"\b(?:int)\s+(tup_\w+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                      # raises if the .so or any symbol is missing
+    assert lib.tup_abi_version() == _lib.ABI_VERSION
+    for name in declared:
+        assert hasattr(lib, name)
+
+
+def test_plugin_surface_matches_reference_contract():
+    mod = importlib.import_module("models.FastTransformer.model")
+    sig = inspect.signature(mod.TransformerModel.__init__)
+    assert [p for p in sig.parameters][1:] == ["in_channels", "base_channels", "transformer_dim", "num_window_blocks",
+                                               "num_heads", "mlp_ratio", "dropout", "window_size"]
+    fsig = inspect.signature(mod.TransformerModel.forward)
+    assert [p for p in fsig.parameters][1:] == ["x", "res_out", "upscale_factor", "require_ratio"]
+    assert fsig.parameters["res_out"].default == (1080, 1920) and fsig.parameters["require_ratio"].default is True
+    m = mod.TransformerModel()
+    from transformerupscaler_amd.weights import param_shapes
+    sd = m.state_dict()
+    keys = [k for k in sd if not k.endswith("relative_position_index")]
+    assert keys == list(param_shapes().keys())
+    assert all(tuple(sd[k].shape) == s for k, s in param_shapes().items())
+    assert sum(p.numel() for p in m.parameters()) == 6447379
+    idx = sd["window_blocks.0.attn.relative_position_index"]
+    assert idx.dtype == torch.int64 and idx[0, 0] == 112 and idx.max() == 224
+    with pytest.raises(RuntimeError):          # no silent CPU path
+        m(torch.rand(1, 3, 16, 16), upscale_factor=2)
+    with pytest.raises(ValueError):            # utils.py:96-97
+        m(torch.rand(1, 3, 16, 16), res_out=(80, 80))
+
+
+def test_checkpoint_roundtrip_and_latest(tmp_path, det_sd):
+    from tools.utils import get_latest_checkpoint
+    mod = importlib.import_module("models.FastTransformer.model")
+    m = mod.TransformerModel()
+    m.load_state_dict(det_sd, strict=False)
+    for e in (1, 2, 10):
+        torch.save(m.state_dict(), tmp_path / f"model_epoch_{e}.pth")     # train.py:152-156 naming
+    path, epoch = get_latest_checkpoint(str(tmp_path))
+    assert epoch == 10 and path.endswith("model_epoch_10.pth")
+    m2 = mod.TransformerModel()
+    m2.load_state_dict(torch.load(path, map_location="cpu"))               # strict, train.py:90
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def _emulate_conv_c64(x_nhwc, wp, bp, r):
+    """What conv3x3_c64_kernel<4,0> computes from the packed operands (fp32 emulation)."""
+    from transformerupscaler_amd.packing import _PERM64
+    B, H, W, _ = x_nhwc.shape
+    xp = F.pad(x_nhwc.permute(0, 3, 1, 2), (1, 1, 1, 1))
+    out = torch.zeros(B, H * r, W * r, 64)
+    inv = torch.empty(64, dtype=torch.long); inv[_PERM64] = torch.arange(64)
+    for nt in range(r * r):
+        acc = torch.zeros(B, 64, H, W)
+        for tap in range(9):
+            dy, dx = tap // 3, tap % 3
+            acc += torch.einsum("nc,bchw->bnhw", wp[nt, tap].float(), xp[:, :, dy:dy + H, dx:dx + W])
+        acc = acc[:, inv] + bp[nt].view(1, 64, 1, 1)          # row n_local holds channel perm[n_local]
+        out[:, nt // r::r, nt % r::r, :] = acc.permute(0, 2, 3, 1)
+    return out
+
+
+@pytest.mark.parametrize("r", [1, 2, 3])
+def test_conv_packing_layout(r):
+    from transformerupscaler_amd import packing
+    g = torch.Generator().manual_seed(r)
+    x = torch.rand((1, 64, 6, 7), generator=g)
+    w, b = torch.rand((64 * r * r, 64, 3, 3), generator=g) - 0.5, torch.rand((64 * r * r,), generator=g)
+    wp, bp = packing.pack_conv_c64(w, b, r)
+    ref = F.pixel_shuffle(F.conv2d(x, w.to(torch.bfloat16).float(), b, padding=1), r).permute(0, 2, 3, 1)
+    got = _emulate_conv_c64(x.permute(0, 2, 3, 1), wp, bp, r)
+    assert (got - ref).abs().max() < 1e-4
+
+
+def test_patch_and_linear_packing_layout():
+    from transformerupscaler_amd import packing
+    from transformerupscaler_amd.packing import _PERM64
+    g = torch.Generator().manual_seed(0)
+    inv = torch.empty(64, dtype=torch.long); inv[_PERM64] = torch.arange(64)
+    unperm = lambda t: t.view(-1, 64, t.shape[-1])[:, inv].reshape(t.shape)      # rows back to natural order
+    w = torch.rand((192, 64, 8, 8), generator=g) - 0.5
+    feat = torch.rand((1, 64, 16, 24), generator=g)
+    wt = unperm(packing.pack_patch_embed(w).float())                  # [192][(i*8+j)*64+c]
+    patches = feat.unfold(2, 8, 8).unfold(3, 8, 8)                    # [1][c][ty][tx][i][j]
+    a = patches.permute(0, 2, 3, 4, 5, 1).reshape(-1, 4096)
+    ref = F.conv2d(feat, w.to(torch.bfloat16).float(), None, stride=8).permute(0, 2, 3, 1).reshape(-1, 192)
+    assert (a @ wt.t() - ref).abs().max() < 1e-3
+    wu = torch.rand((192, 64, 8, 8), generator=g) - 0.5
+    tok = torch.rand((1, 192, 2, 3), generator=g)
+    wtu = unperm(packing.pack_patch_unembed(wu).float())              # [(i*8+j)*64+o][192]
+    y = (tok.permute(0, 2, 3, 1).reshape(-1, 192) @ wtu.t()).view(1, 2, 3, 8, 8, 64)    # [b][ty][tx][i][j][o]
+    y = y.permute(0, 5, 1, 3, 2, 4).reshape(1, 64, 16, 24)
+    refu = F.conv_transpose2d(tok, wu.to(torch.bfloat16).float(), None, stride=8)
+    assert (y - refu).abs().max() < 1e-3
+
+
+def test_resize_taps_match_oracle_and_aten():
+    from oracle import fast_transformer_oracle as O
+    from transformerupscaler_amd.resize_taps import aa_taps
+    for i, o in ((1440, 1080), (2560, 1920), (72, 54), (40, 47), (64, 48)):
+        lo, n, w, k = aa_taps(i, o)
+        lo2, n2, w2 = O.aa_bilinear_taps(i, o)
+        assert (lo == lo2).all() and (n == n2).all() and k == w2.shape[1]
+        assert abs(w - w2).max() == 0.0

@@ -72,13 +72,15 @@ int tup_relpos_bias_expand(const float* table, float* frag, void* stream);
  * qkv bf16 [nwin][64][576]; out bf16 [nwin][64][192]. */
 int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, void* stream);
 
-/* nn.Linear family model.py:79,81,146-151 with fused epilogues.
+/* nn.Linear family model.py:79,81,146-151 with fused epilogues (forward AND the input-gradient
+ * GEMMs of the backward, which are the same product with the transposed weight packed as Wt).
  * Wt bf16 [N][K] (rows permuted per 64-group: row ct*16+4g+e = feature g*16+ct*4+e), bias fp32 [N].
- * a_dtype 0: A bf16 [M][lda]; 1: A fp32.  epilogue 0: +bias -> bf16 | 1: +bias, erf-GELU -> bf16
- * (model.py:148) | 2: +bias + res -> fp32 (residual adds model.py:164,171). */
+ * a_dtype 0: A bf16 [M][lda]; 1: A fp32.  epilogue 0: (+bias) -> bf16 | 1: +bias, erf-GELU -> bf16
+ * (model.py:148) | 2: +bias + res -> fp32 (residual adds model.py:164,171) | 3: * gelu'(aux) -> bf16
+ * (aux bf16 [M][ldo] = saved pre-activation; backward of model.py:148). */
 int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
-                        const float* res, void* out, int ldo, int M, int N, int K, int epilogue,
-                        void* stream);
+                        const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
+                        int epilogue, void* stream);
 
 /* reflect pad + patch_embed Conv2d(64,192,k8,s8) + NHWC permute + zero token pad +
  * window_partition: model.py:256-261,268-285.  feat bf16 NHWC; Wt bf16 [192][4096],
@@ -91,6 +93,43 @@ int tup_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, flo
  * skip/out bf16 NHWC [B][H][W][64]. */
 int tup_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip,
                           void* out, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward (what torch autograd executes for the same call sites under train.py:138).
+ * Accumulating outputs (documented per function) must be zeroed by the caller.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Weight gradient of a Linear: out[NI][NJ] (fp32, ldo) += P^T Q, P [M][NI], Q [M][NJ]; dtypes 0 = bf16,
+ * 1 = fp32.  For nn.Linear: P = grad_output, Q = input -> out = weight.grad layout [out][in]. */
+int tup_gemm_wgrad(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
+                   float* out, int ldo, int M, int NI, int NJ, void* stream);
+
+/* Weight gradient of patch_embed (reflect=1: P = grad tokens, map = feat) and of patch_unembed
+ * (reflect=0: P = tokens, map = grad of its output).  out fp32 [192][4096] +=, column (i*8+j)*64+c. */
+int tup_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int reflect, void* stream);
+
+/* Bias gradients: out[N] += column sums of G [M][N] (dtype 0 bf16 / 1 fp32). */
+int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, void* stream);
+
+/* LayerNorm backward: dx = LN'(gy) (+ gres), dgamma/dbeta fp32 [192] +=. */
+int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
+                      int M, void* stream);
+
+/* Dense relative-position bias in the second (query-row) fragment order used by the backward. */
+int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream);
+
+/* Attention-core backward (recomputes P): gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] +=. */
+int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
+                        void* gqkv, float* dbias_t, int nwin, void* stream);
+
+/* dense bias gradient -> relative_position_bias_table.grad fp32 [225][12] (overwritten). */
+int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream);
+
+/* Input gradients of patch_unembed (gx fp32 window layout, overwritten) and patch_embed (gmap_pad bf16
+ * NHWC [B][ceil8(H)][ceil8(W)][64], the reflect-PADDED map, overwritten). */
+int tup_patch_unembed_bwd(const void* gmap, const void* Wt, float* gx, int B, int H, int W, void* stream);
+int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_pad, int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -167,3 +167,104 @@ def test_patch_embed_unembed(dev, hw):
     refu = (F.conv_transpose2d(t, bf(wu), bu, stride=8)[:, :, :H, :W] + feat).permute(0, 2, 3, 1)
     gotu = ops.patch_unembed(xw.to(dev), packing.pack_patch_unembed(wu).to(dev), bu.to(dev), nhwc)
     close(gotu, refu, 2e-2, 1e-2, "patch unembed + skip")
+
+
+# ------------------------------------------------------------------------------------------------
+# backward kernels vs torch autograd on the same (bf16-rounded) operands
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,NI,NJ,pd,qd", [(200, 192, 64, "bf16", "bf16"), (1000, 576, 192, "bf16", "bf16"),
+                                           (333, 192, 768, "f32", "bf16"), (64, 64, 64, "f32", "f32")])
+def test_gemm_wgrad_and_colsum(dev, M, NI, NJ, pd, qd):
+    from transformerupscaler_amd import ops
+    P, Q = rnd((M, NI), 30), rnd((M, NJ), 31)
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}
+    ref = bf(P).t() @ bf(Q)
+    got = ops.gemm_wgrad(P.to(dt[pd]).to(dev), Q.to(dt[qd]).to(dev))
+    close(got, ref, 2e-3 * (M ** 0.5), 1e-3, "wgrad")
+    src = P.to(dt[pd])
+    close(ops.colsum(src.to(dev)), src.float().sum(0), 1e-3, 1e-4, "colsum")
+
+
+def test_gemm_gelu_bwd_and_fp32_a(dev):
+    from transformerupscaler_amd import ops, packing
+    M, N, K = 192, 768, 192
+    a, w, pre = rnd((M, K), 32), rnd((N, K), 33, 0.08), rnd((M, N), 34, 2.0)
+    wp = packing.pack_linear(w).to(dev)
+    prer = bf(pre).requires_grad_(True)
+    torch.nn.functional.gelu(prer).backward(F.linear(bf(a), bf(w)))
+    got = ops.gemm_tokens(a.to(dev), wp, None, "gelu_bwd", aux=pre.to(torch.bfloat16).to(dev))      # fp32 A
+    close(got, prer.grad, 1e-2, 1e-2, "gelu bwd epilogue")
+    close(ops.gemm_tokens(a.to(dev), wp, None, "bf16"), F.linear(bf(a), bf(w)), 1e-2, 1e-2, "fp32 A, no bias")
+
+
+def test_layernorm_bwd(dev):
+    from transformerupscaler_amd import ops
+    M = 300
+    x = rnd((M, 192), 35, 2.0, 0.3).requires_grad_(True)
+    gm, bt = rnd((192,), 36, 0.1, 1.0).requires_grad_(True), rnd((192,), 37, 0.1).requires_grad_(True)
+    gy, gres = bf(rnd((M, 192), 38)), rnd((M, 192), 39)
+    F.layer_norm(x, (192,), gm, bt, 1e-5).backward(gy)
+    _, mean, rstd = ops.layernorm(x.detach().to(dev), gm.detach().to(dev), bt.detach().to(dev), save_stats=True)
+    dx, dg, db = ops.layernorm_bwd(gy.to(torch.bfloat16).to(dev), x.detach().to(dev), mean, rstd, gm.detach().to(dev), gres.to(dev))
+    close(dx, x.grad + gres, 2e-5, 1e-4, "ln dx")
+    close(dg, gm.grad, 2e-4, 1e-4, "ln dgamma")
+    close(db, bt.grad, 2e-4, 1e-4, "ln dbeta")
+
+
+def test_window_attention_bwd(dev, det_sd):
+    from transformerupscaler_amd import ops
+    nwin = 150          # > 128 slots: exercises the persistent loop
+    qkv = bf(rnd((nwin, 64, 576), 40, 1.5)).requires_grad_(True)
+    table = det_sd["window_blocks.1.attn.relative_position_bias_table"].clone().requires_grad_(True)
+    idx = O.relative_position_index(8)
+    q, k, v = qkv.view(nwin, 64, 3, 12, 16).permute(2, 0, 3, 1, 4)
+    attn = (q * 0.25) @ k.transpose(-2, -1) + table[idx.view(-1)].view(64, 64, 12).permute(2, 0, 1).unsqueeze(0)
+    out = (attn.softmax(-1) @ v).transpose(1, 2).reshape(nwin * 64, 192)
+    gout = bf(rnd((nwin * 64, 192), 41))
+    out.backward(gout)
+    tb = table.detach().to(dev)
+    gqkv, dtable = ops.window_attn_bwd(qkv.detach().view(-1, 576).to(torch.bfloat16).to(dev), gout.to(torch.bfloat16).to(dev),
+                                       ops.relpos_bias_expand(tb), ops.relpos_bias_expand_n(tb))
+    close(gqkv, qkv.grad.view(-1, 576), 2e-2, 2e-2, "attention dqkv")
+    close(dtable, table.grad, 5e-2, 2e-2, "dtable")
+
+
+@pytest.mark.parametrize("hw", [(20, 28), (68, 84), (64, 64)])
+def test_patch_embed_unembed_bwd(dev, hw):
+    from transformerupscaler_amd import ops, packing
+    H, W = hw
+    B = 2
+    # ---- patch_embed backward: d feat (padded map) and d weight ----
+    feat = bf(rnd((B, 64, H, W), 42)).requires_grad_(True)
+    w = bf(rnd((192, 64, 8, 8), 43, 0.02)).requires_grad_(True)
+    ph, pw = (8 - H % 8) % 8, (8 - W % 8) % 8
+    fp = F.pad(feat, (0, pw, 0, ph), mode="reflect") if (ph or pw) else feat
+    fp.retain_grad()
+    tok = F.conv2d(fp, w, None, stride=8).permute(0, 2, 3, 1)
+    ht, wt = tok.shape[1:3]
+    pb, pr = (8 - ht % 8) % 8, (8 - wt % 8) % 8
+    tokp = F.pad(tok.permute(0, 3, 1, 2), (0, pr, 0, pb)).permute(0, 2, 3, 1).contiguous()
+    xw = O.window_partition(tokp, 8).reshape(-1, 192)
+    gx = rnd(tuple(xw.shape), 44)
+    xw.backward(gx)
+    wt_bwd = packing.pack_linear(w.detach().permute(2, 3, 1, 0).reshape(4096, 192)).to(dev)     # rows (i,j,c), cols n
+    gmap = ops.patch_embed_bwd(gx.to(dev), wt_bwd, B, H, W)
+    ref_pad = fp.grad if (ph or pw) else feat.grad
+    close(gmap, ref_pad.permute(0, 2, 3, 1), 1e-2, 1e-2, "patch_embed d(padded feat)")
+    nhwc = feat.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    dw = ops.patch_wgrad(gx.to(dev), nhwc, reflect=True).cpu().view(192, 8, 8, 64).permute(0, 3, 1, 2)
+    close(dw, w.grad, 3e-2, 2e-2, "patch_embed dW")
+
+    # ---- patch_unembed backward: d tokens and d weight ----
+    wu = bf(rnd((192, 64, 8, 8), 45, 0.05)).requires_grad_(True)
+    xs = bf(rnd(tuple(xw.shape), 46)).requires_grad_(True)
+    t = O.window_reverse(xs.view(B, -1, 64, 192), 8, ht + pb, wt + pr)[:, :ht, :wt, :].permute(0, 3, 1, 2)
+    y = F.conv_transpose2d(t, wu, None, stride=8)[:, :, :H, :W]
+    gy = bf(rnd(tuple(y.shape), 47))
+    y.backward(gy)
+    gnhwc = gy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    wt_ub = packing.pack_linear(wu.detach().permute(0, 2, 3, 1).reshape(192, 4096)).to(dev)      # rows k, cols (i,j,o)
+    gxs = ops.patch_unembed_bwd(gnhwc, wt_ub)
+    close(gxs, xs.grad, 2e-2, 1e-2, "patch_unembed d tokens")
+    dwu = ops.patch_wgrad(xs.detach().to(dev), gnhwc, reflect=False).cpu().view(192, 8, 8, 64).permute(0, 3, 1, 2)
+    close(dwu, wu.grad, 3e-2, 2e-2, "patch_unembed dW")

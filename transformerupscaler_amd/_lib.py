@@ -27,9 +27,19 @@ SIGNATURES = {
     "tup_layernorm_fwd": [P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand": [P, P, P],
     "tup_window_attn_fwd": [P, P, P, I, P],
-    "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, I, I, I, I, I, P],
+    "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, P, I, I, I, I, I, P],
     "tup_patch_embed_fwd": [P, P, P, P, I, I, I, P],
     "tup_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
+    # backward
+    "tup_gemm_wgrad": [P, I, I, P, I, I, P, I, I, I, I, P],
+    "tup_patch_wgrad": [P, P, P, I, I, I, I, P],
+    "tup_colsum": [P, I, I, P, I, I, P],
+    "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],
+    "tup_relpos_bias_expand_n": [P, P, P],
+    "tup_window_attn_bwd": [P, P, P, P, P, P, I, P],
+    "tup_relpos_bias_reduce": [P, P, P],
+    "tup_patch_unembed_bwd": [P, P, P, I, I, I, P],
+    "tup_patch_embed_bwd": [P, P, P, I, I, I, P],
 }
 
 

@@ -1,0 +1,331 @@
+// Backward of LayerNorm and of the window-attention core (gfx950).  Replaces what autograd runs for
+// reference models/FastTransformer/model.py:114-130 (attention) and :142,144,163,169 (LayerNorm) under
+// train.py:138.
+//
+// Attention backward: one wave per (window, head), persistent over windows so that the per-head
+// dS sum (the relative-position-bias gradient) accumulates in registers.  Nothing N x N is stored
+// by the forward; P is recomputed from q, k and the dense bias.  Two register orientations of the
+// 64x64 tiles are used so that every product is a v_mfma_f32_16x16x16_bf16 whose B operand is an
+// accumulator tile converted in place:
+//   T-layout (rows = key, cols = query):  dQ^T = K^T dS^T,   dBias += dS^T
+//   N-layout (rows = query, cols = key):  dV^T = dO^T P,     dK^T = Q^T dS
+// Row statistics (max, 1/sum, rowsum(P*dP)) are computed once in the T-layout, where a query is a
+// lane column, and moved to the N-layout with lane shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int DIM = 192, HEADS = 12, HD = 16, NTOK = 64;
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const bf16_t* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ gres,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M)
+{
+    const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    f32x4 gm[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) gm[q] = *reinterpret_cast<const f32x4*>(gamma + q * 64 + sub * 4);
+    float dg[12], db[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+
+    for (int row0 = blockIdx.x * 16; row0 < M; row0 += gridDim.x * 16) {
+        const int row = row0 + slot;
+        const bool ok = row < M;
+        const int r = ok ? row : 0;
+        const float mu = mean[r], rs = rstd[r];
+        float xh[12], gg[12], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int c = q * 64 + sub * 4;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * DIM + c);
+            const u32x2 gv = *reinterpret_cast<const u32x2*>(gy + (size_t)r * DIM + c);
+            const float gyv[4] = {__builtin_bit_cast(float, gv[0] << 16), __builtin_bit_cast(float, gv[0] & 0xffff0000u),
+                                  __builtin_bit_cast(float, gv[1] << 16), __builtin_bit_cast(float, gv[1] & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = q * 4 + e;
+                xh[i] = (xv[e] - mu) * rs;
+                gg[i] = gyv[e] * gm[q][e];
+                s1 += gg[i];
+                s2 += gg[i] * xh[i];
+                if (ok) { dg[i] += gyv[e] * xh[i]; db[i] += gyv[e]; }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        s1 *= (1.0f / DIM); s2 *= (1.0f / DIM);
+        if (ok) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int c = q * 64 + sub * 4;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (gg[q * 4 + e] - s1 - xh[q * 4 + e] * s2);
+                if (gres) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(gres + (size_t)row * DIM + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
+                }
+                *reinterpret_cast<f32x4*>(dx + (size_t)row * DIM + c) = o;
+            }
+        }
+    }
+    // reduce the 16 row slots of the block, then one atomic per column
+    __shared__ float red[2][16][DIM];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][slot][q * 64 + sub * 4 + e] = dg[q * 4 + e];
+            red[1][slot][q * 64 + sub * 4 + e] = db[q * 4 + e];
+        }
+    __syncthreads();
+    if (threadIdx.x < DIM) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { a += red[0][s][threadIdx.x]; b += red[1][s][threadIdx.x]; }
+        atomicAdd(dgamma + threadIdx.x, a);
+        atomicAdd(dbeta + threadIdx.x, b);
+    }
+}
+
+// N-layout copy of the dense bias: fragN[h][qt][kt][lane][e] = bias(query 16qt+4g+e, key 16kt+l16)
+__global__ void relpos_expand_n_kernel(const float* __restrict__ table, float* __restrict__ frag)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= HEADS * 16 * 256) return;
+    const int e = idx & 3, lane = (idx >> 2) & 63, kt = (idx >> 8) & 3, qt = (idx >> 10) & 3, h = idx >> 12;
+    const int qi = 16 * qt + 4 * (lane >> 4) + e, kj = 16 * kt + (lane & 15);
+    const int rel = ((qi >> 3) - (kj >> 3) + 7) * 15 + ((qi & 7) - (kj & 7) + 7);
+    frag[idx] = table[rel * HEADS + h];
+}
+
+// dtable[rel][h] = sum over (query, key) pairs with that relative offset of the dense T-layout gradient
+__global__ void relpos_reduce_kernel(const float* __restrict__ dfrag, float* __restrict__ dtable)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 225 * HEADS) return;
+    const int h = idx % HEADS, rel = idx / HEADS;
+    const int dy = rel / 15 - 7, dx = rel % 15 - 7;      // query - key offsets
+    float s = 0.f;
+    for (int ky = 0; ky < 8; ++ky) {
+        const int qy = ky + dy;
+        if (qy < 0 || qy > 7) continue;
+        for (int kx = 0; kx < 8; ++kx) {
+            const int qx = kx + dx;
+            if (qx < 0 || qx > 7) continue;
+            const int qi = qy * 8 + qx, kj = ky * 8 + kx;
+            const int lane = ((kj >> 2) & 3) * 16 + (qi & 15);
+            s += dfrag[((((size_t)h * 4 + (kj >> 4)) * 4 + (qi >> 4)) * 64 + lane) * 4 + (kj & 3)];
+        }
+    }
+    dtable[idx] = s;      // idx = rel*HEADS + h
+}
+
+// The LDS tiles are private to a wave and waves of a block run different trip counts, so the
+// write->read hand-off is ordered per wave (DS ops of one wave execute in order), not by s_barrier.
+TUP_DEVICE void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+TUP_DEVICE s16x4 to_bf16x4(const f32x4 v) {
+    const u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    return __builtin_bit_cast(s16x4, p);
+}
+
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ gout, const float* __restrict__ bias_t,
+    const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_t, int nwin, int nslots)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4][3][NTOK * HD];     // per wave: K, Q, dO as [tok][hd]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    const int gw = blockIdx.x * 4 + wave;
+    const int h = gw % HEADS, slot = gw / HEADS;
+    bf16_t* kl = lds[wave][0];
+    bf16_t* ql = lds[wave][1];
+    bf16_t* dol = lds[wave][2];
+
+    f32x4 dbacc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dbacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int win = slot; win < nwin; win += nslots) {
+        const bf16_t* base = qkv + (size_t)win * NTOK * (3 * DIM) + h * HD;
+        const bf16_t* gbase = gout + (size_t)win * NTOK * DIM + h * HD;
+        // stage K, Q, dO rows (lane = token) for the transposed (gather) fragments
+        {
+            const bf16_t* r = base + (size_t)lane * (3 * DIM);
+            *reinterpret_cast<u32x4*>(ql + lane * HD) = *reinterpret_cast<const u32x4*>(r);
+            *reinterpret_cast<u32x4*>(ql + lane * HD + 8) = *reinterpret_cast<const u32x4*>(r + 8);
+            *reinterpret_cast<u32x4*>(kl + lane * HD) = *reinterpret_cast<const u32x4*>(r + DIM);
+            *reinterpret_cast<u32x4*>(kl + lane * HD + 8) = *reinterpret_cast<const u32x4*>(r + DIM + 8);
+            const bf16_t* gr = gbase + (size_t)lane * DIM;
+            *reinterpret_cast<u32x4*>(dol + lane * HD) = *reinterpret_cast<const u32x4*>(gr);
+            *reinterpret_cast<u32x4*>(dol + lane * HD + 8) = *reinterpret_cast<const u32x4*>(gr + 8);
+        }
+        // row-fragments [tok 16t+p][d 4g..4g+3], usable as A (row = tok) or as B (col = tok)
+        s16x4 qf[4], kf[4], vf[4], dof[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t roff = (size_t)(16 * t + p) * (3 * DIM) + 4 * g;
+            qf[t] = *reinterpret_cast<const s16x4*>(base + roff);
+            kf[t] = *reinterpret_cast<const s16x4*>(base + roff + DIM);
+            vf[t] = *reinterpret_cast<const s16x4*>(base + roff + 2 * DIM);
+            dof[t] = *reinterpret_cast<const s16x4*>(gbase + (size_t)(16 * t + p) * DIM + 4 * g);
+        }
+        wave_lds_sync();
+        // column-fragments [d p][tok 16t+4g+j] (A operands of the transposed products)
+        s16x4 kT[4], qT[4], doT[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x4 a, b, c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tok = 16 * t + 4 * g + j;
+                a[j] = kl[tok * HD + p]; b[j] = ql[tok * HD + p]; c[j] = dol[tok * HD + p];
+            }
+            kT[t] = __builtin_bit_cast(s16x4, a); qT[t] = __builtin_bit_cast(s16x4, b); doT[t] = __builtin_bit_cast(s16x4, c);
+        }
+
+        // ---------------- T-layout pass, one query tile (16 columns) at a time ----------------
+        float mrow[4], irow[4], drow[4];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            f32x4 st[4], dpt[4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(bias_t + ((((size_t)h * 4 + kt) * 4 + qt) * 64 + lane) * 4);
+                const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                dpt[kt] = mfma16x16x16(vf[kt], dof[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st[kt][e] = s[e] * 0.25f + bf[e]; mx = fmaxf(mx, st[kt][e]); }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            float dsum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { st[kt][e] *= inv; dsum += st[kt][e] * dpt[kt][e]; }
+            dsum += __shfl_xor(dsum, 16);
+            dsum += __shfl_xor(dsum, 32);
+            mrow[qt] = mx; irow[qt] = inv; drow[qt] = dsum;
+            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                f32x4 ds;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ds[e] = st[kt][e] * (dpt[kt][e] - dsum); dbacc[kt][qt][e] += ds[e]; }
+                dq = mfma16x16x16(kT[kt], to_bf16x4(ds), dq);      // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+            }
+            bf16_t* o = gqkv + ((size_t)win * NTOK + 16 * qt + p) * (3 * DIM) + h * HD + 4 * g;
+            *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(dq[0] * 0.25f, dq[1] * 0.25f), pack_bf16x2(dq[2] * 0.25f, dq[3] * 0.25f)};
+        }
+
+        // ---------------- N-layout pass: rows = query 16qt+4g+e, cols = key 16kt+p ----------------
+        f32x4 dvT[4], dkT[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { dvT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dkT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            float mr[4], ir[4], dr[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mr[e] = __shfl(mrow[qt], 4 * g + e);
+                ir[e] = __shfl(irow[qt], 4 * g + e);
+                dr[e] = __shfl(drow[qt], 4 * g + e);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 bf = *reinterpret_cast<const f32x4*>(bias_n + ((((size_t)h * 4 + qt) * 4 + kt) * 64 + lane) * 4);
+                const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+                f32x4 pr, ds;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pr[e] = __expf(s[e] * 0.25f + bf[e] - mr[e]) * ir[e];
+                    ds[e] = pr[e] * (dp[e] - dr[e]);
+                }
+                dvT[kt] = mfma16x16x16(doT[qt], to_bf16x4(pr), dvT[kt]);   // dV^T[d][key] += dO^T[d][query] P[query][key]
+                dkT[kt] = mfma16x16x16(qT[qt], to_bf16x4(ds), dkT[kt]);    // dK^T[d][key] += Q^T[d][query] dS[query][key]
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            bf16_t* o = gqkv + ((size_t)win * NTOK + 16 * kt + p) * (3 * DIM) + h * HD + 4 * g;
+            *reinterpret_cast<u32x2*>(o + DIM) = u32x2{pack_bf16x2(dkT[kt][0] * 0.25f, dkT[kt][1] * 0.25f),
+                                                      pack_bf16x2(dkT[kt][2] * 0.25f, dkT[kt][3] * 0.25f)};
+            *reinterpret_cast<u32x2*>(o + 2 * DIM) = u32x2{pack_bf16x2(dvT[kt][0], dvT[kt][1]), pack_bf16x2(dvT[kt][2], dvT[kt][3])};
+        }
+        wave_lds_sync();      // LDS tiles are overwritten by the next window
+    }
+
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(dbias_t + ((((size_t)h * 4 + kt) * 4 + qt) * 64 + lane) * 4 + e, dbacc[kt][qt][e]);
+}
+
+}  // namespace
+
+// dx = LN'(gy) [+ gres]; dgamma/dbeta (fp32 [192]) are accumulated (caller zeroes them).
+extern "C" int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
+                                 int M, void* stream)
+{
+    if (M <= 0) return 0;
+    int blocks = (M + 15) / 16;
+    if (blocks > 1024) blocks = 1024;
+    layernorm_bwd_kernel<<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Dense bias in the N-layout fragment order (backward only): fp32 [12][4 qt][4 kt][64][4].
+extern "C" int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream)
+{
+    relpos_expand_n_kernel<<<dim3(HEADS * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(table, frag);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// qkv bf16 [nwin][64][576], gout bf16 [nwin][64][192] (grad of the attention output before proj) ->
+// gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] accumulated (caller zeroes).
+extern "C" int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
+                                   void* gqkv, float* dbias_t, int nwin, void* stream)
+{
+    if (nwin <= 0) return 0;
+    int nslots = nwin < 128 ? nwin : 128;
+    const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
+    window_attn_bwd_kernel<<<dim3(nwaves / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, dbias_t, nwin, nslots);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// dense T-layout bias gradient -> relative_position_bias_table gradient fp32 [225][12] (overwritten).
+extern "C" int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream)
+{
+    relpos_reduce_kernel<<<dim3((225 * HEADS + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(dbias_t, dtable);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

@@ -18,7 +18,7 @@
 namespace {
 
 enum { A_BF16 = 0, A_F32 = 1, A_PATCH = 2 };
-enum { E_BF16 = 0, E_GELU_BF16 = 1, E_RES_F32 = 2, E_PATCH_EMBED = 3, E_UNEMBED = 4 };
+enum { E_BF16 = 0, E_GELU_BF16 = 1, E_RES_F32 = 2, E_PATCH_EMBED = 3, E_UNEMBED = 4, E_GELU_BWD = 5 };
 
 struct GemmParams {
     const void* A; int lda;
@@ -26,7 +26,8 @@ struct GemmParams {
     const float* bias;           // [N] natural order (E_UNEMBED: [64])
     void* out; int ldo;
     const float* res;            // E_RES_F32: [M][ldo] fp32
-    const bf16_t* skip;          // E_UNEMBED: NHWC feat to add
+    const bf16_t* skip;          // E_UNEMBED: NHWC feat to add (or null); E_GELU_BWD: pre-activation [M][ldo]
+    int reflect;                 // A_PATCH: 1 = reflect-pad beyond the map, 0 = zeros
     int M, N, K;
     int H, W, Ht, Wt_, nWx, nWy; // geometry for the patch modes (token rows are in window layout)
 };
@@ -98,10 +99,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
                 // k chunk kc = patch pixel (i, j); reflect-pad rows/cols beyond the map (model.py:256-261)
                 const int i = kc >> 3, j = kc & 7;
                 int py = apy[u] + i, px = apx[u] + j;
-                if (py >= p.H) py = 2 * p.H - 2 - py;
-                if (px >= p.W) px = 2 * p.W - 2 - px;
+                bool ok = avalid[u];
+                if (p.reflect) {
+                    if (py >= p.H) py = 2 * p.H - 2 - py;
+                    if (px >= p.W) px = 2 * p.W - 2 - px;
+                } else if (py >= p.H || px >= p.W) {
+                    ok = false; py = 0; px = 0;
+                }
                 const bf16_t* s = (const bf16_t*)p.A + (((size_t)abat[u] * p.H + py) * p.W + px) * 64 + achunk * 8;
-                areg[u] = avalid[u] ? *reinterpret_cast<const u32x4*>(s) : u32x4{0u, 0u, 0u, 0u};
+                areg[u] = ok ? *reinterpret_cast<const u32x4*>(s) : u32x4{0u, 0u, 0u, 0u};
             }
         }
 #pragma unroll
@@ -181,7 +187,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
             uint32_t pk[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float a = v[2 * q] + p.bias[nb + 2 * q], b = v[2 * q + 1] + p.bias[nb + 2 * q + 1];
+                float a = v[2 * q], b = v[2 * q + 1];
+                if (p.bias) { a += p.bias[nb + 2 * q]; b += p.bias[nb + 2 * q + 1]; }
                 if constexpr (EPI == E_GELU_BF16) { a = gelu_erf(a); b = gelu_erf(b); }
                 pk[q] = pack_bf16x2(a, b);
             }
@@ -207,24 +214,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
             for (int q = 0; q < 4; ++q) {
                 f32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + p.bias[nb + 4 * q + e] : 0.f;
+                for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + (p.bias ? p.bias[nb + 4 * q + e] : 0.f) : 0.f;
                 *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
             }
+        } else if constexpr (EPI == E_GELU_BWD) {
+            // out = acc * gelu'(pre), pre = saved fc1 output before the activation (model.py:148)
+            const bf16_t* pr = p.skip + (size_t)m * p.ldo + nb;
+            const u32x4 a0 = *reinterpret_cast<const u32x4*>(pr), a1 = *reinterpret_cast<const u32x4*>(pr + 8);
+            uint32_t pk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t sw = (q < 4) ? a0[q & 3] : a1[q & 3];
+                const float xa = __builtin_bit_cast(float, sw << 16), xb = __builtin_bit_cast(float, sw & 0xffff0000u);
+                pk[q] = pack_bf16x2(v[2 * q] * gelu_erf_grad(xa), v[2 * q + 1] * gelu_erf_grad(xb));
+            }
+            bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
+            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         } else {  // E_UNEMBED: n tile = patch pixel (i, j); features = base channel o
             const TokPos t = token_of_row(m, p);
             const int pix = n0 >> 6, i = pix >> 3, j = pix & 7;
             const int py = t.ty * 8 + i, px = t.tx * 8 + j;
             if (!t.valid || py >= p.H || px >= p.W) continue;
             const size_t off = (((size_t)t.b * p.H + py) * p.W + px) * 64 + g * 16;
-            const u32x4 s0 = *reinterpret_cast<const u32x4*>(p.skip + off);
-            const u32x4 s1 = *reinterpret_cast<const u32x4*>(p.skip + off + 8);
+            u32x4 s0 = {0u, 0u, 0u, 0u}, s1 = {0u, 0u, 0u, 0u};
+            if (p.skip) {
+                s0 = *reinterpret_cast<const u32x4*>(p.skip + off);
+                s1 = *reinterpret_cast<const u32x4*>(p.skip + off + 8);
+            }
             uint32_t pk[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const uint32_t sw = (q < 4) ? s0[q & 3] : s1[q & 3];
                 const float sa = __builtin_bit_cast(float, sw << 16);
                 const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
-                pk[q] = pack_bf16x2(v[2 * q] + p.bias[g * 16 + 2 * q] + sa, v[2 * q + 1] + p.bias[g * 16 + 2 * q + 1] + sb);
+                const float ba = p.bias ? p.bias[g * 16 + 2 * q] : 0.f, bb = p.bias ? p.bias[g * 16 + 2 * q + 1] : 0.f;
+                pk[q] = pack_bf16x2(v[2 * q] + ba + sa, v[2 * q + 1] + bb + sb);
             }
             bf16_t* o = (bf16_t*)p.out + off;
             *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
@@ -247,20 +272,30 @@ int launch(const GemmParams& p, hipStream_t s)
 
 }  // namespace
 
-// epilogue: 0 = +bias -> bf16, 1 = +bias, erf-GELU -> bf16, 2 = +bias +res(fp32) -> fp32.
-// a_dtype: 0 = bf16 A, 1 = fp32 A (converted to bf16 on the way into LDS).
+// epilogue: 0 = (+bias) -> bf16, 1 = +bias, erf-GELU -> bf16, 2 = +bias +res(fp32) -> fp32,
+//           3 = * gelu'(aux) -> bf16 (aux = bf16 [M][ldo] pre-activation; backward of model.py:148).
+// a_dtype: 0 = bf16 A, 1 = fp32 A (converted to bf16 on the way into LDS).  bias may be NULL for 0 and 3.
 extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
-                                   const float* res, void* out, int ldo, int M, int N, int K, int epilogue,
-                                   void* stream)
+                                   const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
+                                   int epilogue, void* stream)
 {
     GemmParams p{};
     p.A = A; p.lda = lda; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.ldo = ldo; p.res = res;
+    p.skip = (const bf16_t*)aux;
     p.M = M; p.N = N; p.K = K;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (a_dtype == 0 && epilogue == 0) return launch<A_BF16, E_BF16>(p, s);
-    if (a_dtype == 0 && epilogue == 1) return launch<A_BF16, E_GELU_BF16>(p, s);
-    if (a_dtype == 0 && epilogue == 2) return launch<A_BF16, E_RES_F32>(p, s);
-    if (a_dtype == 1 && epilogue == 0) return launch<A_F32, E_BF16>(p, s);
+    if ((epilogue == 1 || epilogue == 2) && !bias) return (int)hipErrorInvalidValue;
+    if (epilogue == 2 && !res) return (int)hipErrorInvalidValue;
+    if (epilogue == 3 && !aux) return (int)hipErrorInvalidValue;
+    if (a_dtype == 0) {
+        if (epilogue == 0) return launch<A_BF16, E_BF16>(p, s);
+        if (epilogue == 1) return launch<A_BF16, E_GELU_BF16>(p, s);
+        if (epilogue == 2) return launch<A_BF16, E_RES_F32>(p, s);
+        if (epilogue == 3) return launch<A_BF16, E_GELU_BWD>(p, s);
+    } else if (a_dtype == 1) {
+        if (epilogue == 0) return launch<A_F32, E_BF16>(p, s);
+        if (epilogue == 3) return launch<A_F32, E_GELU_BWD>(p, s);
+    }
     return (int)hipErrorInvalidValue;
 }
 
@@ -273,7 +308,7 @@ extern "C" int tup_patch_embed_fwd(const void* feat, const void* Wt, const float
     p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = feat; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = x_out; p.ldo = 192;
-    p.M = B * p.nWy * p.nWx * 64; p.N = 192; p.K = 4096;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 192; p.K = 4096; p.reflect = 1;
     // reflect padding needs pad < dim (same constraint as F.pad(mode='reflect'))
     if ((p.Ht * 8 - H) >= H || (p.Wt_ * 8 - W) >= W) return (int)hipErrorInvalidValue;
     return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
@@ -288,6 +323,33 @@ extern "C" int tup_patch_unembed_fwd(const float* x, const void* Wt, const float
     p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = x; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
+    return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Backward of patch_unembed w.r.t. its input tokens (model.py:292-305 under autograd): gather the 8x8
+// patches of the gradient map (zero beyond the cropped H x W) and multiply by W^T.
+// gmap bf16 NHWC [B][H][W][64]; Wt bf16 [192][4096] (row k, col (i*8+j)*64+o, rows permuted per
+// 64-group); gx fp32 window layout [M][192] (zero rows for padded tokens).
+extern "C" int tup_patch_unembed_bwd(const void* gmap, const void* Wt, float* gx, int B, int H, int W, void* stream)
+{
+    GemmParams p{};
+    p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
+    p.A = gmap; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = gx; p.ldo = 192;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 192; p.K = 4096; p.reflect = 0;
+    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Backward of patch_embed w.r.t. the (reflect-padded) feature map (model.py:256-285 under autograd):
+// gx fp32 window layout [M][192]; Wt bf16 [4096][192] (row (i*8+j)*64+c, rows permuted per 64-group);
+// gmap_pad bf16 NHWC [B][Ht*8][Wt*8][64] -- the PADDED map; the caller folds the reflected rows/cols back.
+extern "C" int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_pad, int B, int H, int W, void* stream)
+{
+    GemmParams p{};
+    p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8; p.H = p.Ht * 8; p.W = p.Wt_ * 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
+    p.A = gx; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = gmap_pad; p.skip = nullptr;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }

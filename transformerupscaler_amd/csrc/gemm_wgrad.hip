@@ -1,0 +1,222 @@
+// Weight-gradient GEMMs of the token path (gfx950): out[i][j] += sum_m P[m][i] * Q[m][j].
+//
+// The reduction runs over token rows m, which is the slow axis of both operands in memory, so both
+// MFMA fragments need a transpose: tiles are staged row-major into swizzled LDS and read back with
+// ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, delivered column-major), which is
+// exactly the A / B fragment of v_mfma_f32_16x16x16_bf16.  M is split over gridDim.z; partial
+// results are added to the fp32 output with global float atomics (64-B segments).
+//
+// Autograd call sites replaced (reference train.py:138 backward through):
+//   nn.Linear weights     model.py:79,81,146-151   P = grad_out [M][N], Q = layer input [M][K]
+//   patch_embed weight    model.py:215,268          P = grad tokens, Q = 8x8 patches of feat (gather)
+//   patch_unembed weight  model.py:225,302          P = tokens, Q = 8x8 patches of grad map (gather)
+#include "common.h"
+
+namespace {
+
+enum { OP_BF16 = 0, OP_F32 = 1, OP_PATCH = 2 };
+
+struct WgradParams {
+    const void* P; int ldp;      // [M][NI] bf16 or fp32
+    const void* Q; int ldq;      // [M][NJ] bf16 / fp32, or NHWC bf16 map for OP_PATCH
+    float* out; int ldo;         // [NI][NJ] fp32, accumulated
+    int M, NI, NJ, mchunk;
+    int H, W, Ht, Wt_, nWx, nWy, reflect;   // OP_PATCH geometry (token rows in window layout)
+};
+
+TUP_DEVICE s16x4 lds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int PMODE, int QMODE>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];   // [buf][P|Q][64 rows][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int mbeg = blockIdx.z * p.mchunk;
+    const int mend = min(p.M, mbeg + p.mchunk);
+    if (mbeg >= mend) return;
+    const int nsteps = (mend - mbeg + 63) / 64;
+
+    // staging: thread -> chunk (tid&7) of rows (tid>>3) and (tid>>3)+32
+    const int chunk = tid & 7;
+    u32x4 preg[(PMODE == OP_F32) ? 4 : 2], qreg[(QMODE == OP_F32) ? 4 : 2];
+
+    auto load_plain = [&](const void* base, int ld, int col0, int m, bool f32, u32x4* r) {
+        const bool ok = m < mend;
+        if (!f32) {
+            r[0] = ok ? *reinterpret_cast<const u32x4*>((const bf16_t*)base + (size_t)m * ld + col0 + chunk * 8)
+                      : u32x4{0u, 0u, 0u, 0u};
+        } else {
+            const float* s = (const float*)base + (size_t)m * ld + col0 + chunk * 8;
+            r[0] = ok ? *reinterpret_cast<const u32x4*>(s) : u32x4{0u, 0u, 0u, 0u};
+            r[1] = ok ? *reinterpret_cast<const u32x4*>(s + 4) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto load_patch = [&](int m, u32x4* r) {
+        // column block j0 = patch pixel (i, j); 64 channels
+        bool ok = m < mend;
+        const int tok = m & 63;
+        int win = m >> 6;
+        const int wx = win % p.nWx; win /= p.nWx;
+        const int wy = win % p.nWy;
+        const int b = win / p.nWy;
+        const int ty = wy * 8 + (tok >> 3), tx = wx * 8 + (tok & 7);
+        ok = ok && ty < p.Ht && tx < p.Wt_;
+        const int pix = j0 >> 6;
+        int py = ty * 8 + (pix >> 3), px = tx * 8 + (pix & 7);
+        if (p.reflect) {
+            if (py >= p.H) py = 2 * p.H - 2 - py;
+            if (px >= p.W) px = 2 * p.W - 2 - px;
+        } else {
+            ok = ok && py < p.H && px < p.W;
+        }
+        r[0] = ok ? *reinterpret_cast<const u32x4*>((const bf16_t*)p.Q + (((size_t)b * p.H + py) * p.W + px) * 64 + chunk * 8)
+                  : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int m = mbeg + s * 64 + (tid >> 3) + 32 * u;
+            constexpr int PS = (PMODE == OP_F32) ? 2 : 1, QS = (QMODE == OP_F32) ? 2 : 1;
+            load_plain(p.P, p.ldp, i0, m, PMODE == OP_F32, &preg[u * PS]);
+            if constexpr (QMODE == OP_PATCH) load_patch(m, &qreg[u * QS]);
+            else load_plain(p.Q, p.ldq, j0, m, QMODE == OP_F32, &qreg[u * QS]);
+        }
+    };
+    auto cvt = [&](const u32x4* r, bool f32) -> u32x4 {
+        if (!f32) return r[0];
+        const f32x4 lo = __builtin_bit_cast(f32x4, r[0]), hi = __builtin_bit_cast(f32x4, r[1]);
+        return u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int row = (tid >> 3) + 32 * u;
+            constexpr int PS = (PMODE == OP_F32) ? 2 : 1, QS = (QMODE == OP_F32) ? 2 : 1;
+            char* base = smem + buf * (2 * 64 * 128);
+            *reinterpret_cast<u32x4*>(base + swz128(row, chunk)) = cvt(&preg[u * PS], PMODE == OP_F32);
+            *reinterpret_cast<u32x4*>(base + 64 * 128 + swz128(row, chunk)) = cvt(&qreg[u * QS], QMODE == OP_F32);
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addressing: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
+    const int trq = l16 >> 2, trp = l16 & 3;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_stage(s + 1);
+        const char* pb = smem + buf * (2 * 64 * 128);
+        const char* qb = pb + 64 * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = 16 * ks + 4 * g + trq;
+            const int pcol = 16 * wave + 4 * trp;
+            const s16x4 af = lds_read_tr16(pb + swz128(row, pcol >> 3) + (pcol & 7) * 2);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int qcol = 16 * jt + 4 * trp;
+                const s16x4 bfr = lds_read_tr16(qb + swz128(row, qcol >> 3) + (qcol & 7) * 2);
+                acc[jt] = mfma16x16x16(af, bfr, acc[jt]);
+            }
+        }
+        if (s + 1 < nsteps) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[row = i 4g+e][col = j l16]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            atomicAdd(p.out + (size_t)(i0 + 16 * wave + 4 * g + e) * p.ldo + j0 + 16 * jt + l16, acc[jt][e]);
+}
+
+// column sums: out[n] += sum_m G[m][n]
+template <bool F32>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, int ld, float* __restrict__ out, int M, int N, int mchunk)
+{
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
+    float s = 0.f;
+    if (n < N)
+        for (int m = mbeg + sub; m < mend; m += 4)
+            s += F32 ? ((const float*)G)[(size_t)m * ld + n] : bf16_to_f32(((const bf16_t*)G)[(size_t)m * ld + n]);
+    __shared__ float red[4][64];
+    red[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+template <int PMODE, int QMODE>
+int launch(WgradParams p, hipStream_t s)
+{
+    if (p.M <= 0) return 0;
+    if (p.NI % 64 || p.NJ % 64) return (int)hipErrorInvalidValue;
+    const int blocks_ij = (p.NI / 64) * (p.NJ / 64);
+    int msplit = (1024 + blocks_ij - 1) / blocks_ij;
+    const int maxsplit = (p.M + 63) / 64;
+    if (msplit > maxsplit) msplit = maxsplit;
+    if (msplit < 1) msplit = 1;
+    p.mchunk = (((p.M + msplit - 1) / msplit) + 63) / 64 * 64;
+    msplit = (p.M + p.mchunk - 1) / p.mchunk;
+    gemm_wgrad_kernel<PMODE, QMODE><<<dim3(p.NI / 64, p.NJ / 64, msplit), dim3(256), 0, s>>>(p);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// out[NI][NJ] (fp32, ldo) += P^T Q.  p_dtype / q_dtype: 0 = bf16, 1 = fp32.  The caller zeroes `out`.
+extern "C" int tup_gemm_wgrad(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
+                              float* out, int ldo, int M, int NI, int NJ, void* stream)
+{
+    WgradParams p{};
+    p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.out = out; p.ldo = ldo; p.M = M; p.NI = NI; p.NJ = NJ;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (p_dtype == 0 && q_dtype == 0) return launch<OP_BF16, OP_BF16>(p, s);
+    if (p_dtype == 1 && q_dtype == 0) return launch<OP_F32, OP_BF16>(p, s);
+    if (p_dtype == 0 && q_dtype == 1) return launch<OP_BF16, OP_F32>(p, s);
+    if (p_dtype == 1 && q_dtype == 1) return launch<OP_F32, OP_F32>(p, s);
+    return (int)hipErrorInvalidValue;
+}
+
+// out[192][4096] += P^T patches(map): P fp32 [M][192] token rows (window layout), map NHWC bf16
+// [B][H][W][64]; column (i*8+j)*64 + c.  reflect = 1 for patch_embed's weight (reflect-padded
+// forward input), 0 for patch_unembed's weight (cropped output -> zero outside).
+extern "C" int tup_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W,
+                               int reflect, void* stream)
+{
+    WgradParams p{};
+    p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8; p.reflect = reflect;
+    p.P = P; p.ldp = 192; p.Q = map; p.out = out; p.ldo = 4096;
+    p.M = B * p.nWy * p.nWx * 64; p.NI = 192; p.NJ = 4096;
+    return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// out[N] += column sums of G [M][N] (bias gradients).
+extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, void* stream)
+{
+    if (M <= 0 || N <= 0) return 0;
+    int msplit = 256;
+    int mchunk = (M + msplit - 1) / msplit;
+    if (mchunk < 64) mchunk = 64;
+    msplit = (M + mchunk - 1) / mchunk;
+    dim3 grid((N + 63) / 64, msplit);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == 1) colsum_kernel<true><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk);
+    else colsum_kernel<false><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

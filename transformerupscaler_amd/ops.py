@@ -134,13 +134,14 @@ def window_attn(qkv, bias_frag):
     return out
 
 
-def gemm_tokens(a, wt, bias, epilogue, res=None, out=None):
-    """epilogue 'bf16' | 'gelu' | 'res' (fp32 out = a@wt^T + bias + res)."""
+def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None):
+    """epilogue 'bf16' | 'gelu' | 'res' (fp32 out = a@wt^T + bias + res) | 'gelu_bwd' (bf16 out = (a@wt^T) * gelu'(aux))."""
     M, K = a.shape
     N = wt.shape[0]
     assert tuple(wt.shape) == (N, K) and N % 64 == 0 and K % 64 == 0
     a_dtype = {BF16: 0, F32: 1}[a.dtype]
-    epi = {"bf16": 0, "gelu": 1, "res": 2}[epilogue]
+    epi = {"bf16": 0, "gelu": 1, "res": 2, "gelu_bwd": 3}[epilogue]
+    resp = auxp = None
     if epi == 2:
         if out is None:
             out = torch.empty((M, N), dtype=F32, device=a.device)
@@ -148,9 +149,10 @@ def gemm_tokens(a, wt, bias, epilogue, res=None, out=None):
         resp = _chk(res, F32, (M, N), "res")
     else:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
-        resp = None
+        if epi == 3:
+            auxp = _chk(aux, BF16, (M, N), "aux")
     _lib.call("tup_gemm_tokens_fwd", _chk(a, a.dtype, None, "a"), a_dtype, K, _chk(wt, BF16, None, "wt"),
-              _chk(bias, F32, (N,), "bias"), resp, out.data_ptr(), N, M, N, K, epi, _stream())
+              _opt(bias, F32, (N,), "bias"), resp, auxp, out.data_ptr(), N, M, N, K, epi, _stream())
     return out
 
 
@@ -179,3 +181,85 @@ def patch_unembed(x, wt, bias, skip):
     _lib.call("tup_patch_unembed_fwd", _chk(x, F32, (B * nwy * nwx * 64, 192), "x"), _chk(wt, BF16, (4096, 192), "wt"),
               _chk(bias, F32, (64,), "bias"), _chk(skip, BF16, None, "skip"), out.data_ptr(), B, H, W, _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# backward wrappers
+# ------------------------------------------------------------------------------------------------
+def gemm_wgrad(p, q, out=None):
+    """out[NI][NJ] fp32 (+)= p^T q; p [M][NI], q [M][NJ] (bf16 or fp32)."""
+    M, NI = p.shape
+    NJ = q.shape[1]
+    assert q.shape[0] == M and NI % 64 == 0 and NJ % 64 == 0
+    if out is None:
+        out = torch.zeros((NI, NJ), dtype=F32, device=p.device)
+    _lib.call("tup_gemm_wgrad", _chk(p, p.dtype, None, "p"), {BF16: 0, F32: 1}[p.dtype], NI,
+              _chk(q, q.dtype, None, "q"), {BF16: 0, F32: 1}[q.dtype], NJ, _chk(out, F32, (NI, NJ), "out"), NJ,
+              M, NI, NJ, _stream())
+    return out
+
+
+def patch_wgrad(p, fmap, reflect):
+    B, H, W, C = fmap.shape
+    _, _, nwy, nwx = window_geometry(H, W)
+    out = torch.zeros((192, 4096), dtype=F32, device=p.device)
+    _lib.call("tup_patch_wgrad", _chk(p, F32, (B * nwy * nwx * 64, 192), "p"), _chk(fmap, BF16, None, "map"),
+              out.data_ptr(), B, H, W, int(reflect), _stream())
+    return out
+
+
+def colsum(g, out=None):
+    M, N = g.shape
+    if out is None:
+        out = torch.zeros((N,), dtype=F32, device=g.device)
+    _lib.call("tup_colsum", _chk(g, g.dtype, None, "g"), {BF16: 0, F32: 1}[g.dtype], N, _chk(out, F32, (N,), "out"),
+              M, N, _stream())
+    return out
+
+
+def layernorm_bwd(gy, x, mean, rstd, gamma, gres=None):
+    M = x.shape[0]
+    dx = torch.empty((M, 192), dtype=F32, device=x.device)
+    dg = torch.zeros((192,), dtype=F32, device=x.device)
+    db = torch.zeros((192,), dtype=F32, device=x.device)
+    _lib.call("tup_layernorm_bwd", _chk(gy, BF16, (M, 192), "gy"), _chk(x, F32, (M, 192), "x"), _chk(mean, F32, (M,), "mean"),
+              _chk(rstd, F32, (M,), "rstd"), _chk(gamma, F32, (192,), "gamma"), _opt(gres, F32, (M, 192), "gres"),
+              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, _stream())
+    return dx, dg, db
+
+
+def relpos_bias_expand_n(table):
+    frag = torch.empty((12, 4, 4, 64, 4), dtype=F32, device=table.device)
+    _lib.call("tup_relpos_bias_expand_n", _chk(table, F32, (225, 12), "table"), frag.data_ptr(), _stream())
+    return frag
+
+
+def window_attn_bwd(qkv, gout, bias_t, bias_n):
+    """returns (gqkv bf16 [M][576], dtable fp32 [225][12])."""
+    M = qkv.shape[0]
+    assert M % 64 == 0
+    gqkv = torch.empty((M, 576), dtype=BF16, device=qkv.device)
+    dbias = torch.zeros((12, 4, 4, 64, 4), dtype=F32, device=qkv.device)
+    _lib.call("tup_window_attn_bwd", _chk(qkv, BF16, (M, 576), "qkv"), _chk(gout, BF16, (M, 192), "gout"),
+              _chk(bias_t, F32, (12, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (12, 4, 4, 64, 4), "bias_n"),
+              gqkv.data_ptr(), dbias.data_ptr(), M // 64, _stream())
+    dtable = torch.empty((225, 12), dtype=F32, device=qkv.device)
+    _lib.call("tup_relpos_bias_reduce", dbias.data_ptr(), dtable.data_ptr(), _stream())
+    return gqkv, dtable
+
+
+def patch_unembed_bwd(gmap, wt):
+    B, H, W, C = gmap.shape
+    _, _, nwy, nwx = window_geometry(H, W)
+    gx = torch.empty((B * nwy * nwx * 64, 192), dtype=F32, device=gmap.device)
+    _lib.call("tup_patch_unembed_bwd", _chk(gmap, BF16, None, "gmap"), _chk(wt, BF16, (192, 4096), "wt"),
+              gx.data_ptr(), B, H, W, _stream())
+    return gx
+
+
+def patch_embed_bwd(gx, wt, B, H, W):
+    ht, wt_, nwy, nwx = window_geometry(H, W)
+    gmap = torch.empty((B, ht * 8, wt_ * 8, 64), dtype=BF16, device=gx.device)
+    _lib.call("tup_patch_embed_bwd", _chk(gx, F32, (B * nwy * nwx * 64, 192), "gx"), _chk(wt, BF16, (4096, 192), "wt"),
+              gmap.data_ptr(), B, H, W, _stream())
+    return gmap

@@ -28,20 +28,25 @@ int tup_abi_version(void);
 
 /* conv1: Conv2d(3,64,k3,p1)+ReLU. model.py:202-203,251.
  * x fp32 [B][3][H][W]; wp bf16 [64][32] (row ct*16+4g+e = channel g*16+ct*4+e, k = tap*3+cin,
- * zero pad 27..31); bias fp32 [64]; out bf16 NHWC. */
-int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* bias, void* out,
-                       int B, int H, int W, int relu, void* stream);
+ * zero pad 27..31); bias fp32 [64] or NULL; out bf16 NHWC.
+ * Also the input-gradient conv of the 64->3 convs (transposed/flipped weight as wp): in_mask fp32
+ * (shape of x; input *= in_mask > 0) and out_mask bf16 NHWC (out *= out_mask > 0) fuse the ReLU backward. */
+int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* bias, const float* in_mask,
+                       const void* out_mask, void* out, int B, int H, int W, int relu, void* stream);
 
-/* Conv2d(64, Cout, k3, p1) on NHWC bf16:
+/* Conv2d(64*in_r^2, Cout, k3, p1) on NHWC bf16:
  *   conv2 model.py:204,252 | decoder_conv1 model.py:228,312 | Upsampler convs + PixelShuffle(r)
  *   utils.py:62-63,74-75,83-84 (out_mode 0, ntiles = r*r, the cout tile index is the sub-pixel
  *   i*r+j) | up1_conv utils.py:32-40 and decoder_conv2 model.py:229,313 (out_mode 1).
- * wp bf16 [ntiles][9][rows][64]; out_mode 0: rows = 64, bias fp32 [ntiles][64] or NULL,
- * out bf16 [B][H*r][W*r][64]; out_mode 1: rows = 16 (cout_valid real), bias fp32 [cout_valid]
- * or NULL, out fp32 [B][cout_valid][H][W]. */
-int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* bias, void* out,
-                        int B, int H, int W, int ntiles, int r, int cout_valid,
-                        int relu, int out_mode, void* stream);
+ * x bf16 [B][H*in_r][W*in_r][64]: in_r = 1 is a plain map; in_r > 1 reads 64*in_r^2 logical channels
+ * through PixelShuffle^-1 (the input-gradient conv of an Upsampler stage).
+ * wp bf16 [ntiles][in_r^2][9][rows][64]; out_mode 0: rows = 64, bias fp32 [ntiles][64] or NULL,
+ * out bf16 [B][H*r][W*r][64], optional add / mask (bf16, shape of out):
+ * out = (conv + bias [relu] + add) * (mask > 0); out_mode 1: rows = 16 (cout_valid real), bias fp32
+ * [cout_valid] or NULL, out fp32 [B][cout_valid][H][W]. */
+int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* bias, const void* add,
+                        const void* mask, void* out, int B, int H, int W, int ntiles, int r,
+                        int cout_valid, int relu, int out_mode, int in_r, void* stream);
 
 /* Planar fp32 Conv2d(3, 3*r*r, k3, p1) + PixelShuffle(r) [+ add] [+ clamp(0,1)]:
  *   final_upscale utils.py:62-63,74-75,83-84 (n_feats=3) | final_upscale_conv model.py:212,317
@@ -77,7 +82,8 @@ int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int 
  * Wt bf16 [N][K] (rows permuted per 64-group: row ct*16+4g+e = feature g*16+ct*4+e), bias fp32 [N].
  * a_dtype 0: A bf16 [M][lda]; 1: A fp32.  epilogue 0: (+bias) -> bf16 | 1: +bias, erf-GELU -> bf16
  * (model.py:148) | 2: +bias + res -> fp32 (residual adds model.py:164,171) | 3: * gelu'(aux) -> bf16
- * (aux bf16 [M][ldo] = saved pre-activation; backward of model.py:148). */
+ * (aux bf16 [M][ldo] = saved pre-activation; backward of model.py:148).  With epilogue 1 a non-NULL
+ * aux is an OUTPUT that receives the bf16 pre-activation (saved for the backward). */
 int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
                         const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
                         int epilogue, void* stream);
@@ -108,8 +114,9 @@ int tup_gemm_wgrad(const void* P, int p_dtype, int ldp, const void* Q, int q_dty
  * (reflect=0: P = tokens, map = grad of its output).  out fp32 [192][4096] +=, column (i*8+j)*64+c. */
 int tup_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int reflect, void* stream);
 
-/* Bias gradients: out[N] += column sums of G [M][N] (dtype 0 bf16 / 1 fp32). */
-int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, void* stream);
+/* Bias gradients: out[N] += column sums of G [M][N] (dtype 0 bf16 / 1 fp32) over the rows with
+ * rowmask[m] != 0 (uint8 [M]; NULL = all rows). */
+int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, const void* rowmask, void* stream);
 
 /* LayerNorm backward: dx = LN'(gy) (+ gres), dgamma/dbeta fp32 [192] +=. */
 int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
@@ -130,6 +137,36 @@ int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream);
  * NHWC [B][ceil8(H)][ceil8(W)][64], the reflect-PADDED map, overwritten). */
 int tup_patch_unembed_bwd(const void* gmap, const void* Wt, float* gx, int B, int H, int W, void* stream);
 int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_pad, int B, int H, int W, void* stream);
+
+/* Weight/bias gradients of the 3x3 convs (accumulating).
+ *   c64:    x bf16 NHWC, gmap bf16 NHWC [B][H*gr][W*gr][64] sub-pixel plane sp -> dwp fp32 [64][9][64]
+ *           (co, tap, ci) for couts {c*gr*gr + sp}, dbias fp32 [64] or NULL
+ *   thin:   gpl fp32 [B][3][H][W] -> dwp fp32 [3][9][64], dbias [3] or NULL   (up1_conv, decoder_conv2)
+ *   c3:     x fp32 [B][3][H][W], gmap bf16 NHWC -> dw fp32 [64][3][3][3], dbias [64]   (conv1)
+ *   planar: x fp32 [B][3][H][W], gpl fp32 [B][3][H*r][W*r] -> dw fp32 [3rr][3][3][3], dbias [3rr] */
+int tup_conv3x3_c64_wgrad(const void* x, const void* gmap, float* dwp, float* dbias,
+                          int B, int H, int W, int gr, int sp, void* stream);
+int tup_conv3x3_thin_wgrad(const void* x, const float* gpl, float* dwp, float* dbias, int B, int H, int W, void* stream);
+int tup_conv3x3_c3_wgrad(const float* x, const void* gmap, float* dw, float* dbias, int B, int H, int W, void* stream);
+int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float* dw, float* dbias,
+                             int B, int H, int W, int r, void* stream);
+
+/* Input gradient of Conv2d(3,3rr,k3)+PixelShuffle(r) on planar fp32 (final_upscale): w fp32 [3rr][3][3][3]. */
+int tup_conv3x3_planar_dgrad(const float* gpl, const float* w, float* gx, int B, int H, int W, int r, void* stream);
+
+/* Backward of Resize(antialias) [+ clamp]: gin fp32 [planes][Hi][Wi]; pre = pre-clamp output or NULL;
+ * oy0/oyn/ox0/oxn: per input row/col the range of outputs that reference it. */
+int tup_resize_aa_bwd(const float* gout, const float* pre, float* gin, const int* ymin, const float* yw, int KY,
+                      const int* xmin, const float* xw, int KX, const int* oy0, const int* oyn,
+                      const int* ox0, const int* oxn, int planes, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* gin = gout * [0 <= pre <= 1] * [relu_src > 0] (clamp / ReLU backward; either source may be NULL). */
+int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, float* gin, long long n, void* stream);
+
+/* Gradient merge at `feat` (model.py:264,268,308 fan-out) + conv2's ReLU backward:
+ * out = (a + b + fold_reflect(gpe)) * (feat > 0), NHWC bf16; gpe = padded map from tup_patch_embed_bwd. */
+int tup_feat_grad_combine(const void* a, const void* b, const void* gpe, const void* feat, void* out,
+                          int B, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,7 @@ def _emulate_conv_c64(x_nhwc, wp, bp, r):
         acc = torch.zeros(B, 64, H, W)
         for tap in range(9):
             dy, dx = tap // 3, tap % 3
-            acc += torch.einsum("nc,bchw->bnhw", wp[nt, tap].float(), xp[:, :, dy:dy + H, dx:dx + W])
+            acc += torch.einsum("nc,bchw->bnhw", wp[nt, 0, tap].float(), xp[:, :, dy:dy + H, dx:dx + W])
         acc = acc[:, inv] + bp[nt].view(1, 64, 1, 1)          # row n_local holds channel perm[n_local]
         out[:, nt // r::r, nt % r::r, :] = acc.permute(0, 2, 3, 1)
     return out

@@ -268,3 +268,118 @@ def test_patch_embed_unembed_bwd(dev, hw):
     close(gxs, xs.grad, 2e-2, 1e-2, "patch_unembed d tokens")
     dwu = ops.patch_wgrad(xs.detach().to(dev), gnhwc, reflect=False).cpu().view(192, 8, 8, 64).permute(0, 3, 1, 2)
     close(dwu, wu.grad, 3e-2, 2e-2, "patch_unembed dW")
+
+
+# ------------------------------------------------------------------------------------------------
+# conv-side backward kernels
+# ------------------------------------------------------------------------------------------------
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("r,hw", [(1, (19, 45)), (2, (16, 40)), (3, (9, 33))])
+def test_conv_c64_backward(dev, r, hw):
+    from transformerupscaler_amd import ops, packing
+    H, W = hw
+    x = bf(rnd((2, 64, H, W), 50)).requires_grad_(True)
+    w = bf(rnd((64 * r * r, 64, 3, 3), 51, 0.06)).requires_grad_(True)
+    b = rnd((64 * r * r,), 52, 0.2).requires_grad_(True)
+    y = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), r)
+    gy = bf(rnd(tuple(y.shape), 53))
+    y.backward(gy)
+    gyd = nhwc(gy).to(dev)
+    gx = ops.conv_c64(gyd, packing.pack_conv_c64_dgrad(w.detach(), r).to(dev), None, 1, in_r=r)
+    close(gx, x.grad.permute(0, 2, 3, 1), 3e-2, 2e-2, f"conv dgrad r={r}")
+    dwp, db = ops.conv_c64_wgrad(nhwc(x.detach()).to(dev), gyd, r)
+    dw, dbb = packing.unpack_conv_c64_wgrad(dwp, db, r)
+    close(dw, w.grad, 3e-2 * (H * W) ** 0.5 / 10, 2e-2, f"conv wgrad r={r}")
+    close(dbb, b.grad, 2e-2, 1e-2, f"conv dbias r={r}")
+    if r == 1:       # fused "+ add" and ReLU-backward mask epilogue
+        add, z = bf(rnd(tuple(x.shape), 54)), bf(rnd(tuple(x.shape), 55))
+        got = ops.conv_c64(gyd, packing.pack_conv_c64_dgrad(w.detach(), 1).to(dev), None, 1, add=nhwc(add).to(dev), mask=nhwc(z).to(dev))
+        close(got, ((x.grad + add) * (z > 0)).permute(0, 2, 3, 1), 3e-2, 2e-2, "dgrad + add + mask")
+
+
+def test_conv_thin_backward(dev):
+    from transformerupscaler_amd import ops, packing
+    x = bf(rnd((2, 64, 21, 50), 56)).requires_grad_(True)
+    w = bf(rnd((3, 64, 3, 3), 57, 0.06)).requires_grad_(True)
+    b = rnd((3,), 58, 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    gy = rnd(tuple(y.shape), 59)
+    y.backward(gy)
+    dwp, db = ops.conv_thin_wgrad(nhwc(x.detach()).to(dev), gy.to(dev), True)
+    close(dwp.permute(0, 2, 1).reshape(3, 64, 3, 3), w.grad, 5e-2, 2e-2, "thin wgrad")
+    close(db, b.grad, 1e-3, 1e-4, "thin dbias")
+    z = bf(rnd(tuple(x.shape), 60))
+    m = rnd(tuple(gy.shape), 61)
+    gx = ops.conv1(gy.to(dev), packing.pack_conv_thin_dgrad(w.detach()).to(dev), None, relu=False)
+    close(gx, x.grad.permute(0, 2, 3, 1), 2e-2, 2e-2, "thin dgrad")
+    # masks: input *= (m > 0), output *= (z > 0)
+    x.grad = None
+    F.conv2d(x, w, b, padding=1).backward(gy * (m > 0))
+    gx = ops.conv1(gy.to(dev), packing.pack_conv_thin_dgrad(w.detach()).to(dev), None, relu=False, in_mask=m.to(dev), out_mask=nhwc(z).to(dev))
+    close(gx, (x.grad * (z > 0)).permute(0, 2, 3, 1), 2e-2, 2e-2, "thin dgrad masked")
+
+
+def test_conv1_wgrad(dev):
+    from transformerupscaler_amd import ops
+    x = rnd((2, 3, 37, 70), 62, 0.5, 0.5)
+    w = rnd((64, 3, 3, 3), 63, 0.3).requires_grad_(True)
+    b = rnd((64,), 64, 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=1)
+    gy = bf(rnd(tuple(y.shape), 65))
+    y.backward(gy)
+    dw, db = ops.conv1_wgrad(x.to(dev), nhwc(gy).to(dev))
+    close(dw, w.grad, 2e-3, 1e-3, "conv1 wgrad")
+    close(db, b.grad, 2e-3, 1e-3, "conv1 dbias")
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 6])
+def test_conv_planar_backward(dev, r):
+    from transformerupscaler_amd import ops, packing
+    x = rnd((2, 3, 23, 70), 66).requires_grad_(True)
+    w = rnd((3 * r * r, 3, 3, 3), 67, 0.3).requires_grad_(True)
+    b = rnd((3 * r * r,), 68, 0.2).requires_grad_(True)
+    y = F.pixel_shuffle(F.conv2d(x, w, b, padding=1), r)
+    gy = rnd(tuple(y.shape), 69)
+    y.backward(gy)
+    dw, db = ops.conv_planar_wgrad(x.detach().to(dev), gy.to(dev), r)
+    close(dw, w.grad, 2e-3, 1e-4, "planar wgrad")
+    close(db, b.grad, 2e-3, 1e-4, "planar dbias")
+    close(ops.conv_planar_dgrad(gy.to(dev), w.detach().to(dev), r), x.grad, 1e-5, 1e-5, "planar dgrad")
+    if r == 1:
+        close(ops.conv_planar(gy.to(dev), packing.pack_planar_dgrad(w.detach()).to(dev), None, 1), x.grad, 1e-5, 1e-5, "planar dgrad via fwd kernel")
+
+
+@pytest.mark.parametrize("sizes", [((72, 96), (54, 72)), ((30, 40), (45, 47)), ((144, 256), (108, 192))])
+def test_resize_and_clamp_backward(dev, sizes):
+    from transformerupscaler_amd import ops
+    (h, w), (oh, ow) = sizes
+    x = rnd((2, 3, h, w), 70, 0.8, 0.5).requires_grad_(True)
+    pre = O.aa_resize(x, (oh, ow))
+    gy = rnd(tuple(pre.shape), 71)
+    pre.clamp(0, 1).backward(gy)
+    close(ops.resize_aa_bwd(gy.to(dev), (h, w), pre=pre.detach().to(dev)), x.grad, 3e-6, 1e-5, "resize+clamp bwd")
+    x.grad = None
+    O.aa_resize(x, (oh, ow)).backward(gy)
+    close(ops.resize_aa_bwd(gy.to(dev), (h, w)), x.grad, 3e-6, 1e-5, "resize bwd")
+    relu_src = rnd(tuple(gy.shape), 72)
+    close(ops.mask_bwd(gy.to(dev), pre=pre.detach().to(dev), relu_src=relu_src.to(dev)),
+          gy * ((pre >= 0) & (pre <= 1)) * (relu_src > 0), 0, 0, "mask bwd")
+
+
+@pytest.mark.parametrize("hw", [(20, 28), (64, 64), (23, 41)])
+def test_feat_grad_combine(dev, hw):
+    from transformerupscaler_amd import ops
+    H, W = hw
+    B = 2
+    hp, wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+    a, b, feat = bf(rnd((B, 64, H, W), 73)), bf(rnd((B, 64, H, W), 74)), bf(rnd((B, 64, H, W), 75))
+    gpe = bf(rnd((B, 64, hp, wp), 76))
+    f = feat.clone().requires_grad_(True)
+    fp = F.pad(f, (0, wp - W, 0, hp - H), mode="reflect") if (hp > H or wp > W) else f
+    fp.backward(gpe)
+    ref = (a + b + f.grad) * (feat > 0)
+    got = ops.feat_grad_combine(nhwc(a).to(dev), nhwc(b).to(dev), nhwc(gpe).to(dev), nhwc(feat).to(dev))
+    close(got, ref.permute(0, 2, 3, 1), 2e-2, 1e-2, "feat grad combine")

@@ -1,0 +1,149 @@
+"""Training path on the MI355X: gradients of every parameter from the hand-written backward vs the
+reference-generated fixture (tests/golden/train_g36x44.npz) and vs the oracle's autograd; Adam step
+semantics (parameters of unused scales untouched).
+
+Tolerances.  Activations / activation-gradients are bf16 with fp32 accumulation.
+ * With a smooth cotangent (loss = sum(out * R), R fixed) every parameter gradient must match the
+   oracle's fp32 autograd to <= 15 % relative L2, median over parameters <= 10 %.  Calibration: the
+   reference graph itself run under torch bf16 autocast on the CPU (same weights / inputs) differs
+   from its fp32 run by 7-13 % (median over parameters) and 15-25 % (worst parameter) relative L2,
+   forward max |diff| 6.5e-3; this path measures 6-8 % median / 8-12 % worst, forward ~1e-3 (the error is dominated by ReLU/clamp
+   mask flips caused by the bf16 forward, which every parameter gradient inherits).
+ * With train.py's L1 loss the cotangent is sign(out - hr)/N, which is discontinuous: a forward
+   difference of 1e-3 (bf16) flips the sign on the ~0.2 % of pixels with |out - hr| < 1e-3 and that
+   alone is a ~4-5 % relative-L2 change of the cotangent.  The fixture comparison therefore allows
+   10 % relative L2 / sampled error (the loss value itself must agree to 2e-3)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fast_transformer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_model(det_sd):
+    m = importlib.import_module("models.FastTransformer.model").TransformerModel()
+    m.load_state_dict(det_sd, strict=False)
+    return m.to("cuda")
+
+
+def train_loss(model, lr, hr):
+    """train.py:117-136 with equal-shaped samples batched (mean of per-sample means == batch mean)."""
+    from transformerupscaler_amd.autograd import resize_aa
+    out = model(lr, res_out=tuple(hr.shape[2:]), require_ratio=False)
+    if tuple(out.shape[2:]) != tuple(hr.shape[2:]):
+        out = resize_aa(out, tuple(hr.shape[2:]))
+    return F.l1_loss(out, hr)
+
+
+def test_train_step_grads_match_reference(det_sd, golden_dir):
+    d = dict(np.load(os.path.join(golden_dir, "train_g36x44.npz")))
+    model = make_model(det_sd).eval()            # eval graph with grads: dropout off, as the fixture
+    loss = train_loss(model, torch.from_numpy(d["lr"]).cuda(), torch.from_numpy(d["hr"]).cuda())
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-3, (loss.item(), float(d["loss"]))
+    none = set(d["none_grads"].tolist())
+    worst = {}
+    for k, p in model.named_parameters():
+        if k in none:
+            assert p.grad is None, f"{k} must not receive a gradient at scale 2"
+            continue
+        assert p.grad is not None, k
+        st = d["gstat_" + k]
+        g = p.grad.detach().double().cpu().flatten()
+        samp = g[torch.from_numpy(d["gidx_" + k])].float().numpy()
+        ref = d["gval_" + k]
+        e_s = np.abs(samp - ref).max() / max(st[2], 1e-12)
+        e_n = abs(g.norm().item() - st[1]) / max(st[1], 1e-12)
+        worst[k] = (e_s, e_n)
+        if "gfull_" + k in d:
+            full = torch.from_numpy(d["gfull_" + k]).double().flatten()
+            rel = (g - full).norm().item() / max(full.norm().item(), 1e-12)
+            assert rel <= 0.10, f"{k}: relative L2 error {rel:.4f}"
+        assert e_s <= 0.10, f"{k}: sampled max err {e_s:.4f} of max|g|"
+        assert e_n <= 0.05, f"{k}: norm err {e_n:.4f}"
+    print("worst sampled:", max(v[0] for v in worst.values()), "worst norm:", max(v[1] for v in worst.values()))
+
+
+@pytest.mark.parametrize("scale,shape,kw", [(4, (1, 3, 20, 28), dict(upscale_factor=4)),
+                                            (3, (2, 3, 24, 40), dict(res_out=(70, 100))),
+                                            (6, (1, 3, 16, 24), dict(upscale_factor=6))])
+def test_grads_fixed_cotangent_vs_oracle(det_sd, scale, shape, kw):
+    """Scales 3/4/6 incl. the in-model resize + clamp path, against the oracle's autograd (CPU fp32),
+    with a smooth loss sum(out * R) so only the backward kernels are under test."""
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(scale))
+    leaf = {k: v.clone().requires_grad_(True) for k, v in det_sd.items()}
+    yo = O.forward(leaf, x, **kw)
+    R = torch.rand(tuple(yo.shape), generator=torch.Generator().manual_seed(99)) - 0.5
+    (yo * R).sum().backward()
+    model = make_model(det_sd).eval()
+    y = model(x.cuda(), **kw)
+    (y * R.cuda()).sum().backward()
+    assert (y.detach().cpu() - yo.detach()).abs().max() <= 2.5e-2
+    errs = {}
+    for k, p in model.named_parameters():
+        ref = leaf[k].grad
+        if ref is None:
+            assert p.grad is None, k
+            continue
+        g = p.grad.detach().cpu().double()
+        errs[k] = (g - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-12)
+    bad = {k: round(v, 4) for k, v in errs.items() if v > 0.15}
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f"scale {scale}: relative L2 median {med:.4f} worst {max(errs.values()):.4f} ({max(errs, key=errs.get)})")
+    assert not bad, bad
+    assert med <= 0.10, med
+
+
+def test_grads_fixed_cotangent_train_geometry(det_sd, golden_dir):
+    """train.py geometry (model at x2 without ratio, external antialiased resize) with a smooth loss."""
+    from transformerupscaler_amd.autograd import resize_aa
+    d = dict(np.load(os.path.join(golden_dir, "train_g36x44.npz")))
+    lr = torch.from_numpy(d["lr"])
+    R = torch.rand((2, 3, 54, 66), generator=torch.Generator().manual_seed(5)) - 0.5
+    leaf = {k: v.clone().requires_grad_(True) for k, v in det_sd.items()}
+    (O.aa_resize(O.forward(leaf, lr, res_out=(54, 66), require_ratio=False), (54, 66)) * R).sum().backward()
+    model = make_model(det_sd).eval()
+    (resize_aa(model(lr.cuda(), res_out=(54, 66), require_ratio=False), (54, 66)) * R.cuda()).sum().backward()
+    errs = {}
+    for k, p in model.named_parameters():
+        if leaf[k].grad is None:
+            assert p.grad is None, k
+            continue
+        g, ref = p.grad.detach().cpu().double(), leaf[k].grad.double()
+        errs[k] = (g - ref).norm().item() / max(ref.norm().item(), 1e-12)
+    bad = {k: round(v, 4) for k, v in errs.items() if v > 0.15}
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f"train geometry: relative L2 median {med:.4f} worst {max(errs.values()):.4f} ({max(errs, key=errs.get)})")
+    assert not bad, bad
+    assert med <= 0.10, med
+
+
+def test_adam_step_skips_unused_scales(det_sd, golden_dir):
+    d = dict(np.load(os.path.join(golden_dir, "train_g36x44.npz")))
+    model = make_model(det_sd).eval()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)          # train.py:104
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    opt.zero_grad()
+    train_loss(model, torch.from_numpy(d["lr"]).cuda(), torch.from_numpy(d["hr"]).cuda()).backward()
+    opt.step()
+    none = set(d["none_grads"].tolist())
+    for k, p in model.named_parameters():
+        if k in none:
+            assert torch.equal(p.detach(), before[k]), k
+        elif "adam_" + k in d:
+            # first Adam step moves every element by ~lr*sign(g): compare the update direction where the
+            # reference gradient is significant (e.g. the key bias of qkv has an exactly-zero true gradient)
+            ref = torch.from_numpy(d["adam_" + k]).cuda()
+            gref = torch.from_numpy(d["gfull_" + k]).cuda()
+            sel = gref.abs() > 0.05 * gref.abs().max()
+            agree = ((p.detach() - before[k]).sign() == (ref - before[k]).sign())[sel].float().mean().item()
+            assert agree >= 0.97, f"{k}: only {agree:.3f} of the significant update signs agree"
+    # second forward uses the updated weights (pack cache invalidated by the in-place update)
+    l2 = train_loss(model, torch.from_numpy(d["lr"]).cuda(), torch.from_numpy(d["hr"]).cuda()).item()
+    assert l2 < float(d["loss"]) + 1e-3

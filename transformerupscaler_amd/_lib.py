@@ -11,7 +11,7 @@ from ctypes import c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtupscale_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 P = c_void_p
 I = c_int
@@ -19,8 +19,8 @@ I = c_int
 # name -> argtypes, mirrors include/tupscale_hip.h one to one
 SIGNATURES = {
     "tup_abi_version": [],
-    "tup_conv3x3_c3_fwd": [P, P, P, P, I, I, I, I, P],
-    "tup_conv3x3_c64_fwd": [P, P, P, P, I, I, I, I, I, I, I, I, P],
+    "tup_conv3x3_c3_fwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "tup_conv3x3_c64_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "tup_conv3x3_planar_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "tup_resize_aa_fwd": [P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P],
     "tup_clamp01_fwd": [P, P, c_longlong, P],
@@ -33,13 +33,21 @@ SIGNATURES = {
     # backward
     "tup_gemm_wgrad": [P, I, I, P, I, I, P, I, I, I, I, P],
     "tup_patch_wgrad": [P, P, P, I, I, I, I, P],
-    "tup_colsum": [P, I, I, P, I, I, P],
+    "tup_colsum": [P, I, I, P, I, I, P, P],
     "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand_n": [P, P, P],
     "tup_window_attn_bwd": [P, P, P, P, P, P, I, P],
     "tup_relpos_bias_reduce": [P, P, P],
     "tup_patch_unembed_bwd": [P, P, P, I, I, I, P],
     "tup_patch_embed_bwd": [P, P, P, I, I, I, P],
+    "tup_conv3x3_c64_wgrad": [P, P, P, P, I, I, I, I, I, P],
+    "tup_conv3x3_thin_wgrad": [P, P, P, P, I, I, I, P],
+    "tup_conv3x3_c3_wgrad": [P, P, P, P, I, I, I, P],
+    "tup_conv3x3_planar_wgrad": [P, P, P, P, I, I, I, I, P],
+    "tup_conv3x3_planar_dgrad": [P, P, P, I, I, I, I, P],
+    "tup_resize_aa_bwd": [P, P, P, P, P, I, P, P, I, P, P, P, P, I, I, I, I, I, P],
+    "tup_mask_bwd": [P, P, P, P, c_longlong, P],
+    "tup_feat_grad_combine": [P, P, P, P, P, I, I, I, P],
 }
 
 

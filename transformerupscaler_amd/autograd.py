@@ -1,0 +1,235 @@
+"""Training path: forward that saves activations + the hand-written backward, as ONE autograd node.
+
+Replaces what torch autograd does for reference models/FastTransformer/model.py:231-327 under
+train.py:113-140: every gradient below is produced by a HIP kernel through the C ABI (ops.py); torch
+only carries the node in its graph, owns the tensors and accumulates ``.grad``.
+
+Dropout (model.py:80-82,127,132,150; p = 0.1 in ``.train()`` mode) is not applied on this path yet:
+the graph is the eval-mode graph, which is also what the parity fixtures use.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops, packing
+from .weights import BLOCKS, active_param_names, upsampler_layout
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+# Optional hook for data-parallel training: called as grad_ready_hook(names: List[str], grads:
+# Dict[str, Tensor]) as soon as a group of parameter gradients is final, in reverse execution order,
+# so a reducer can start its all-reduce while the rest of the backward still runs (dp.py).
+grad_ready_hook: Optional[Callable[[List[str], Dict[str, torch.Tensor]], None]] = None
+
+_ROWMASK_CACHE = {}
+
+
+def _valid_token_rowmask(B, H, W, device):
+    key = (B, H, W, str(device))
+    if key not in _ROWMASK_CACHE:
+        ht, wt, nwy, nwx = ops.window_geometry(H, W)
+        ty = (torch.arange(nwy).view(-1, 1, 1, 1) * 8 + torch.arange(8).view(1, 1, -1, 1))
+        tx = (torch.arange(nwx).view(1, -1, 1, 1) * 8 + torch.arange(8).view(1, 1, 1, -1))
+        m = ((ty < ht) & (tx < wt)).expand(nwy, nwx, 8, 8).reshape(1, -1).expand(B, -1).reshape(-1)
+        _ROWMASK_CACHE[key] = m.to(torch.uint8).contiguous().to(device)
+    return _ROWMASK_CACHE[key]
+
+
+def forward_train(pk, frags_t, x, scale, res_out, require_ratio):
+    """Same stages as engine.forward, keeping what the backward needs in `sv`."""
+    sv = {}
+    x = x.contiguous().float()
+    B, _, H, W = x.shape
+    sv["x"] = x
+    sv["feat1"] = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
+    feat = sv["feat"] = ops.conv_c64(sv["feat1"], pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+    ups = [feat]
+    for si, (_, r) in enumerate(upsampler_layout(scale)):
+        ups.append(ops.conv_c64(ups[-1], pk[f"up1.{si}.w"], pk[f"up1.{si}.b"], r, relu=False))
+    sv["ups"] = ups
+    ui = sv["ui"] = ops.conv_c64_thin(ups[-1], pk["up1_conv.w"], None, 3, relu=True)
+    xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])
+    blocks = []
+    for i in range(BLOCKS):
+        s = {"x_in": xw}
+        s["y1"], s["mean1"], s["rstd1"] = ops.layernorm(xw, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], save_stats=True)
+        s["qkv"] = ops.gemm_tokens(s["y1"], pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
+        s["att"] = ops.window_attn(s["qkv"], frags_t[i])
+        xm = s["x_mid"] = ops.gemm_tokens(s["att"], pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=xw)
+        s["y2"], s["mean2"], s["rstd2"] = ops.layernorm(xm, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], save_stats=True)
+        s["hpre"] = torch.empty((xm.shape[0], 768), dtype=BF16, device=x.device)
+        s["hid"] = ops.gemm_tokens(s["y2"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"], "gelu", aux=s["hpre"])
+        xw = ops.gemm_tokens(s["hid"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"], "res", res=xm)
+        blocks.append(s)
+    sv["blocks"] = blocks
+    sv["xw_out"] = xw
+    comb = sv["comb"] = ops.patch_unembed(xw, pk["pu.w"], pk["pu.b"], feat)
+    dec = sv["dec"] = ops.conv_c64(comb, pk["dec1.w"], pk["dec1.b"], 1, relu=True)
+    res = ops.conv_c64_thin(dec, pk["dec2.w"], pk["dec2.b"], 3, relu=False)
+    ts = [res]
+    for si, (_, r) in enumerate(upsampler_layout(scale)):
+        ts.append(ops.conv_planar(ts[-1], pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r))
+    sv["ts"] = ts
+    hs, ws = H * scale, W * scale
+    needs_resize = bool(require_ratio) and tuple(res_out) != (hs, hs) and tuple(res_out) != (hs, ws)
+    total = ops.conv_planar(ts[-1], pk["fuc.w"], pk["fuc.b"], 1, add=ui, clamp=False)     # pre-clamp sum
+    if needs_resize:
+        pre = ops.resize_aa(total, res_out, clamp=False)
+        sv["resized_from"] = (hs, ws)
+    else:
+        pre = total
+        sv["resized_from"] = None
+    sv["pre"] = pre
+    return ops.clamp01(pre), sv
+
+
+def backward_train(pk, frags_t, frags_n, sv, scale, gout) -> Dict[str, torch.Tensor]:
+    """Returns {reference parameter name: gradient} for the parameters active at `scale`."""
+    g: Dict[str, torch.Tensor] = {}
+
+    def ready(*names):
+        if grad_ready_hook is not None:
+            grad_ready_hook(list(names), g)
+
+    x, feat, ui = sv["x"], sv["feat"], sv["ui"]
+    B, _, H, W = x.shape
+    stages = upsampler_layout(scale)
+    gout = gout.contiguous().float()
+    # ---- clamp (+ resize) ----
+    if sv["resized_from"] is not None:
+        g_sum = ops.resize_aa_bwd(gout, sv["resized_from"], pre=sv["pre"])
+    else:
+        g_sum = ops.mask_bwd(gout, pre=sv["pre"])
+    # ---- final_upscale_conv (3->3) + "+ upscaled_input" ----
+    ts = sv["ts"]
+    g["final_upscale_conv.weight"], g["final_upscale_conv.bias"] = ops.conv_planar_wgrad(ts[-1], g_sum, 1)
+    g_t = ops.conv_planar(g_sum, pk["fuc.wd"], None, 1)
+    ready("final_upscale_conv.weight", "final_upscale_conv.bias")
+    # ---- final_upscale stages (reverse) ----
+    for si in reversed(range(len(stages))):
+        idx, r = stages[si]
+        k = f"final_upscale.upsamplers.{scale}.{idx}"
+        g[k + ".weight"], g[k + ".bias"] = ops.conv_planar_wgrad(ts[si], g_t, r)
+        g_t = ops.conv_planar_dgrad(g_t, pk[f"fu.{si}.raw"], r)
+        ready(k + ".weight", k + ".bias")
+    g_res = g_t                                                   # d residual, planar [B][3][H][W]
+    # ---- decoder_conv2 (64->3) and decoder_conv1's ReLU ----
+    dwp, db = ops.conv_thin_wgrad(sv["dec"], g_res, True)
+    g["decoder_conv2.weight"], g["decoder_conv2.bias"] = dwp.permute(0, 2, 1).reshape(3, 64, 3, 3), db
+    g_dec = ops.conv1(g_res, pk["dec2.wd"], None, relu=False, out_mask=sv["dec"])
+    ready("decoder_conv2.weight", "decoder_conv2.bias")
+    # ---- decoder_conv1 (64->64) ----
+    dwp, db = ops.conv_c64_wgrad(sv["comb"], g_dec, 1)
+    g["decoder_conv1.weight"], g["decoder_conv1.bias"] = packing.unpack_conv_c64_wgrad(dwp, db, 1)
+    g_comb = ops.conv_c64(g_dec, pk["dec1.wd"], None, 1)
+    del g_dec
+    ready("decoder_conv1.weight", "decoder_conv1.bias")
+    # ---- patch_unembed (+ skip) ----
+    g["patch_unembed.bias"] = ops.colsum(g_comb.view(-1, 64))
+    g["patch_unembed.weight"] = ops.patch_wgrad(sv["xw_out"], g_comb, reflect=False).view(192, 8, 8, 64).permute(0, 3, 1, 2)
+    g_x = ops.patch_unembed_bwd(g_comb, pk["pu.wd"])
+    ready("patch_unembed.weight", "patch_unembed.bias")
+    # ---- transformer blocks (reverse) ----
+    for i in reversed(range(BLOCKS)):
+        s, p = sv["blocks"][i], f"window_blocks.{i}"
+        g[p + ".mlp.2.bias"] = ops.colsum(g_x)
+        g[p + ".mlp.2.weight"] = ops.gemm_wgrad(g_x, s["hid"])
+        g_h = ops.gemm_tokens(g_x, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
+        g[p + ".mlp.0.bias"] = ops.colsum(g_h)
+        g[p + ".mlp.0.weight"] = ops.gemm_wgrad(g_h, s["y2"])
+        g_y2 = ops.gemm_tokens(g_h, pk[f"b{i}.fc1.wd"], None, "bf16")
+        del g_h
+        g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"] = ops.layernorm_bwd(
+            g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
+        g[p + ".attn.proj.bias"] = ops.colsum(g_xm)
+        g[p + ".attn.proj.weight"] = ops.gemm_wgrad(g_xm, s["att"])
+        g_att = ops.gemm_tokens(g_xm, pk[f"b{i}.proj.wd"], None, "bf16")
+        g_qkv, g[p + ".attn.relative_position_bias_table"] = ops.window_attn_bwd(s["qkv"], g_att, frags_t[i], frags_n[i])
+        g[p + ".attn.qkv.bias"] = ops.colsum(g_qkv)
+        g[p + ".attn.qkv.weight"] = ops.gemm_wgrad(g_qkv, s["y1"])
+        g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.qkv.wd"], None, "bf16")
+        del g_qkv, g_att
+        g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm_bwd(
+            g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm)
+        ready(*[p + sfx for sfx in (".mlp.2.bias", ".mlp.2.weight", ".mlp.0.bias", ".mlp.0.weight", ".norm2.weight",
+                                    ".norm2.bias", ".attn.proj.bias", ".attn.proj.weight",
+                                    ".attn.relative_position_bias_table", ".attn.qkv.bias", ".attn.qkv.weight",
+                                    ".norm1.weight", ".norm1.bias")])
+    # ---- patch_embed ----
+    g["patch_embed.bias"] = ops.colsum(g_x, rowmask=_valid_token_rowmask(B, H, W, x.device))
+    g["patch_embed.weight"] = ops.patch_wgrad(g_x, feat, reflect=True).view(192, 8, 8, 64).permute(0, 3, 1, 2)
+    g_pe = ops.patch_embed_bwd(g_x, pk["pe.wd"], B, H, W)
+    del g_x
+    ready("patch_embed.weight", "patch_embed.bias")
+    # ---- branch A: up1_conv (ReLU, no bias) and the Upsampler stages ----
+    g_ui = ops.mask_bwd(g_sum, relu_src=ui)
+    ups = sv["ups"]
+    dwp, _ = ops.conv_thin_wgrad(ups[-1], g_ui, False)
+    g["up1_conv.conv.weight"] = dwp.permute(0, 2, 1).reshape(3, 64, 3, 3)
+    g_up = ops.conv1(g_ui, pk["up1_conv.wd"], None, relu=False)
+    ready("up1_conv.conv.weight")
+    for si in reversed(range(len(stages))):
+        idx, r = stages[si]
+        k = f"up1.upsamplers.{scale}.{idx}"
+        dwp, db = ops.conv_c64_wgrad(ups[si], g_up, r)
+        g[k + ".weight"], g[k + ".bias"] = packing.unpack_conv_c64_wgrad(dwp, db, r)
+        g_up = ops.conv_c64(g_up, pk[f"up1.{si}.wd"], None, 1, in_r=r)
+        ready(k + ".weight", k + ".bias")
+    # ---- merge at feat + conv2's ReLU, conv2, conv1 ----
+    g_feat = ops.feat_grad_combine(g_comb, g_up, g_pe, feat)
+    del g_comb, g_up, g_pe
+    dwp, db = ops.conv_c64_wgrad(sv["feat1"], g_feat, 1)
+    g["conv2.weight"], g["conv2.bias"] = packing.unpack_conv_c64_wgrad(dwp, db, 1)
+    g_f1 = ops.conv_c64(g_feat, pk["conv2.wd"], None, 1, mask=sv["feat1"])
+    g["conv1.weight"], g["conv1.bias"] = ops.conv1_wgrad(x, g_f1)
+    ready("conv2.weight", "conv2.bias", "conv1.weight", "conv1.bias")
+    return g
+
+
+class _FastTransformerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, scale, res_out, require_ratio, names, *params):
+        pk, frags_t, frags_n = module.packed(scale, backward=True)
+        out, sv = forward_train(pk, frags_t, x, scale, res_out, require_ratio)
+        ctx.module, ctx.scale, ctx.names, ctx.sv = module, scale, names, sv
+        ctx.pk, ctx.frags = pk, (frags_t, frags_n)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout)
+        ctx.sv = None
+        outs = []
+        for n in ctx.names:
+            gr = grads.get(n)
+            outs.append(None if gr is None else gr.contiguous())
+        return (None, None, None, None, None, None) + tuple(outs)
+
+
+def fast_transformer_function(module, x, scale, res_out, require_ratio):
+    """Only the parameters active at `scale` enter the node, so the other scales' upsamplers keep
+    ``grad is None`` and Adam skips them exactly as in the reference."""
+    named = dict(module.named_parameters())
+    names = [n for n in active_param_names(scale) if named[n].requires_grad]
+    return _FastTransformerFn.apply(module, x, scale, tuple(res_out), bool(require_ratio), names, *[named[n] for n in names])
+
+
+class _ResizeAAFn(torch.autograd.Function):
+    """transforms.Resize on a tensor (train.py:127-130) with a HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_hw = tuple(x.shape[2:])
+        return ops.resize_aa(x.contiguous().float(), tuple(size), clamp=False)
+
+    @staticmethod
+    def backward(ctx, gout):
+        return ops.resize_aa_bwd(gout.contiguous().float(), ctx.in_hw), None
+
+
+def resize_aa(x: torch.Tensor, size) -> torch.Tensor:
+    if tuple(x.shape[2:]) == tuple(size):
+        return x
+    return _ResizeAAFn.apply(x, tuple(size))

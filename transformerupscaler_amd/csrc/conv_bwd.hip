@@ -1,0 +1,565 @@
+// Backward-only kernels of the convolutional side of the FastTransformer path (gfx950): weight /
+// bias gradients of every 3x3 conv, the input gradient of the planar up-convs, the backward of the
+// antialiased resize + clamp, and the gradient merge at `feat`.  They replace what torch autograd
+// runs under reference train.py:138 for model.py:251-265 and :308-327.
+// (Input gradients of the 64-channel convs reuse the forward implicit-GEMM kernels with
+// transposed / flipped weights: conv3x3_c64.hip, conv_thin.hip.)
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, HALO_W = TW + 2, HALO_H = TH + 2, NPIX_HALO = HALO_H * HALO_W;
+constexpr int X_TILE_BYTES = NPIX_HALO * 128;
+
+TUP_DEVICE s16x4 lds_read_tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+TUP_DEVICE void stage_x_halo(char* lds, const bf16_t* xb, int H, int W, int ty0, int tx0, int tid) {
+    for (int idx = tid; idx < NPIX_HALO * 8; idx += 256) {
+        const int q = idx >> 3, c = idx & 7;
+        const int yy = q / HALO_W, xx = q - yy * HALO_W;
+        const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+            v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * 64 + c * 8);
+        *reinterpret_cast<u32x4*>(lds + swz128(q, c)) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW[co][tap][ci] += sum_pixels G[p][co] * X[p + tap][ci]   (64 x 64 channels, MFMA 16x16x16,
+// both operands transposed out of LDS with ds_read_b64_tr_b16).  Persistent over pixel tiles: the
+// whole 64 x 576 partial result lives in registers (144 per lane) and is flushed once.
+// G may be the sub-pixel plane `sp` of a pixel-shuffled gradient [B][H*gr][W*gr][64].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ gmap, float* __restrict__ dwp, float* __restrict__ dbias,
+    int B, int H, int W, int gr, int sp, int tilesX, int tilesY)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* x_lds = smem;
+    char* g_lds = smem + X_TILE_BYTES;          // [256 pixels][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int trq = l16 >> 2, trp = l16 & 3;
+    const int si = sp / gr, sj = sp - si * gr;
+    const int Hg = H * gr, Wg = W * gr;
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    const int ntiles = tilesX * tilesY * B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        stage_x_halo(x_lds, x + (size_t)b * H * W * 64, H, W, ty0, tx0, tid);
+        const bf16_t* gb = gmap + (size_t)b * Hg * Wg * 64;
+        for (int idx = tid; idx < 256 * 8; idx += 256) {
+            const int pix = idx >> 3, c = idx & 7;
+            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (oy < H && ox < W)
+                v = *reinterpret_cast<const u32x4*>(gb + ((size_t)(oy * gr + si) * Wg + (ox * gr + sj)) * 64 + c * 8);
+            *reinterpret_cast<u32x4*>(g_lds + swz128(pix, c)) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < 16; ++ks) {
+            const int ry = ks >> 1, x0 = (ks & 1) * 16;
+            const int gp = ry * 32 + x0 + 4 * g + trq;
+            const int gcol = 16 * wave + 4 * trp;
+            const s16x4 af = lds_read_tr16(g_lds + swz128(gp, gcol >> 3) + (gcol & 7) * 2);
+            {   // bias gradient: this lane holds G[4 pixels][co = 16*wave + l16]
+                const bf16x4 av = __builtin_bit_cast(bf16x4, af);
+                bsum += bf16_to_f32(av[0]) + bf16_to_f32(av[1]) + bf16_to_f32(av[2]) + bf16_to_f32(av[3]);
+            }
+            const int qbase = ry * HALO_W + x0 + 4 * g + trq;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int q = qbase + (tap / 3) * HALO_W + (tap % 3);
+#pragma unroll
+                for (int cit = 0; cit < 4; ++cit) {
+                    const int xcol = 16 * cit + 4 * trp;
+                    const s16x4 bfr = lds_read_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2);
+                    acc[tap][cit] = mfma16x16x16(af, bfr, acc[tap][cit]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // flush: D[row = co 4g+e][col = ci l16]; packed layout [co][tap][ci] keeps 16 lanes on one 64-B segment
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cit = 0; cit < 4; ++cit)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(dwp + ((size_t)(16 * wave + 4 * g + e) * 9 + tap) * 64 + 16 * cit + l16, acc[tap][cit][e]);
+    if (dbias) {
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (g == 0) atomicAdd(dbias + 16 * wave + l16, bsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin convs (cout = 3: up1_conv, decoder_conv2): G planar fp32 [B][3][H][W], X NHWC bf16.
+// dwp[co][tap][ci] += ..., dbias[co] += sum G.  VALU: thread = (ci, tap group), persistent over tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_wgrad_thin_kernel(
+    const bf16_t* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dwp, float* __restrict__ dbias,
+    int B, int H, int W, int tilesX, int tilesY)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* x_lds = smem;
+    float* g_lds = reinterpret_cast<float*>(smem + X_TILE_BYTES);     // [3][256]
+    const int tid = threadIdx.x, ci = tid & 63, tg = tid >> 6;
+    const int tap0 = (tg == 0) ? 0 : 1 + 2 * tg, ntap = (tg == 0) ? 3 : 2;     // {0,1,2},{3,4},{5,6},{7,8}
+    float acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[a][c] = 0.f;
+    float bsum = 0.f;
+    const int ntiles = tilesX * tilesY * B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        stage_x_halo(x_lds, x + (size_t)b * H * W * 64, H, W, ty0, tx0, tid);
+        for (int idx = tid; idx < 3 * 256; idx += 256) {
+            const int co = idx >> 8, pix = idx & 255;
+            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
+            g_lds[idx] = (oy < H && ox < W) ? gpl[(((size_t)b * 3 + co) * H + oy) * W + ox] : 0.f;
+        }
+        __syncthreads();
+        for (int pix = 0; pix < 256; ++pix) {
+            const float g0 = g_lds[pix], g1 = g_lds[256 + pix], g2 = g_lds[512 + pix];
+            const int qb = (pix >> 5) * HALO_W + (pix & 31);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (a < ntap) {
+                    const int tap = tap0 + a;
+                    const int q = qb + (tap / 3) * HALO_W + (tap % 3);
+                    const float xv = bf16_to_f32(*reinterpret_cast<const bf16_t*>(x_lds + swz128(q, ci >> 3) + (ci & 7) * 2));
+                    acc[a][0] = fmaf(g0, xv, acc[a][0]);
+                    acc[a][1] = fmaf(g1, xv, acc[a][1]);
+                    acc[a][2] = fmaf(g2, xv, acc[a][2]);
+                }
+            }
+            if (tid < 3) bsum += g_lds[tid * 256 + pix];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (a < ntap)
+#pragma unroll
+            for (int co = 0; co < 3; ++co) atomicAdd(dwp + ((size_t)co * 9 + tap0 + a) * 64 + ci, acc[a][co]);
+    if (dbias && tid < 3) atomicAdd(dbias + tid, bsum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv1 (3 -> 64): X planar fp32 [B][3][H][W], G NHWC bf16 [B][H][W][64].
+// dw[co][ci][ky][kx] += (PyTorch layout), dbias[co] +=.  thread = (co, tap group).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ gmap, float* __restrict__ dw, float* __restrict__ dbias,
+    int B, int H, int W, int tilesX, int tilesY)
+{
+    __shared__ float x_lds[3][HALO_H][HALO_W + 2];
+    __shared__ __attribute__((aligned(16))) bf16_t g_lds[256 * 64];
+    const int tid = threadIdx.x, co = tid & 63, tg = tid >> 6;
+    const int tap0 = (tg == 0) ? 0 : 1 + 2 * tg, ntap = (tg == 0) ? 3 : 2;
+    float acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[a][c] = 0.f;
+    float bsum = 0.f;
+    const int ntiles = tilesX * tilesY * B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        for (int idx = tid; idx < 3 * NPIX_HALO; idx += 256) {
+            const int c = idx / NPIX_HALO, q = idx - c * NPIX_HALO;
+            const int yy = q / HALO_W, xx = q - yy * HALO_W;
+            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+            x_lds[c][yy][xx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
+        }
+        for (int idx = tid; idx < 256 * 8; idx += 256) {
+            const int pix = idx >> 3, c = idx & 7;
+            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (oy < H && ox < W) v = *reinterpret_cast<const u32x4*>(gmap + (((size_t)b * H + oy) * W + ox) * 64 + c * 8);
+            *reinterpret_cast<u32x4*>(g_lds + pix * 64 + c * 8) = v;
+        }
+        __syncthreads();
+        for (int pix = 0; pix < 256; ++pix) {
+            const float gv = bf16_to_f32(g_lds[pix * 64 + co]);
+            const int py = pix >> 5, px = pix & 31;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (a < ntap) {
+                    const int tap = tap0 + a;
+                    const int yy = py + tap / 3, xx = px + tap % 3;
+                    acc[a][0] = fmaf(gv, x_lds[0][yy][xx], acc[a][0]);
+                    acc[a][1] = fmaf(gv, x_lds[1][yy][xx], acc[a][1]);
+                    acc[a][2] = fmaf(gv, x_lds[2][yy][xx], acc[a][2]);
+                }
+            }
+            if (tg == 0) bsum += gv;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        if (a < ntap)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicAdd(dw + ((size_t)co * 3 + c) * 9 + tap0 + a, acc[a][c]);
+    if (dbias && tg == 0) atomicAdd(dbias + co, bsum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// planar convs (final_upscale 3 -> 3*r*r + PixelShuffle, final_upscale_conv 3 -> 3):
+//   wgrad: dw[co][ci][ky][kx] += sum G_pre[co][p] X[ci][p+tap], dbias[co] += sum G_pre[co][p],
+//          G_pre[c*r*r + sp][y][x] = G[c][y*r+si][x*r+sj]   (G planar fp32 [B][3][H*r][W*r]).
+// One thread per output element (co, ci, tap) / bias, looping over the pixels of an LDS tile.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
+    const float* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dw, float* __restrict__ dbias,
+    int B, int H, int W, int r, int th, int tilesX, int tilesY)
+{
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    const int cout = 3 * r * r, rr = r * r;
+    float* x_lds = fl;                               // [3][th+2][HALO_W]
+    float* g_lds = fl + 3 * (th + 2) * HALO_W;       // [cout][th*32]
+    const int npix = th * 32;
+    const int nout = cout * 28;                      // 27 weights + 1 bias per cout
+    const int tid = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    const int Hr = H * r, Wr = W * r;
+    const int ntiles = tilesX * tilesY * B;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * th, tx0 = tx * TW;
+        for (int idx = tid; idx < 3 * (th + 2) * HALO_W; idx += 256) {
+            const int c = idx / ((th + 2) * HALO_W), q = idx - c * (th + 2) * HALO_W;
+            const int yy = q / HALO_W, xx = q - yy * HALO_W;
+            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+            x_lds[idx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
+        }
+        for (int idx = tid; idx < cout * npix; idx += 256) {
+            const int co = idx / npix, pix = idx - co * npix;
+            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
+            const int c = co / rr, s = co - c * rr;
+            const int si = s / r, sj = s - si * r;
+            g_lds[idx] = (oy < H && ox < W) ? gpl[(((size_t)b * 3 + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int o = tid + i * 256;
+            if (o < nout) {
+                const int co = o / 28, k = o - co * 28;
+                const float* gp = g_lds + co * npix;
+                float s = 0.f;
+                if (k < 27) {
+                    const int ci = k / 9, tap = k - ci * 9;
+                    const float* xp = x_lds + (ci * (th + 2) + tap / 3) * HALO_W + tap % 3;
+                    for (int pix = 0; pix < npix; ++pix) s = fmaf(gp[pix], xp[(pix >> 5) * HALO_W + (pix & 31)], s);
+                } else {
+                    for (int pix = 0; pix < npix; ++pix) s += gp[pix];
+                }
+                acc[i] += s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int o = tid + i * 256;
+        if (o < nout) {
+            const int co = o / 28, k = o - co * 28;
+            if (k < 27) atomicAdd(dw + co * 27 + k, acc[i]);
+            else if (dbias) atomicAdd(dbias + co, acc[i]);
+        }
+    }
+}
+
+// dgrad of a planar up-conv: gx[ci][y][x] = sum_{co,ky,kx} W[co][ci][ky][kx] * G_pre[co][y+1-ky][x+1-kx]
+__global__ __launch_bounds__(256) void conv3x3_dgrad_planar_kernel(
+    const float* __restrict__ gpl, const float* __restrict__ w, float* __restrict__ gx, int H, int W, int r)
+{
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [cout][27] original layout (co, ci, ky, kx)
+    const int cout = 3 * r * r, rr = r * r;
+    for (int i = threadIdx.x; i < cout * 27; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    const int Hr = H * r, Wr = W * r;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int co = 0; co < cout; ++co) {
+        const int c = co / rr, s = co - c * rr;
+        const int si = s / r, sj = s - si * r;
+        const float* gp = gpl + ((size_t)b * 3 + c) * Hr * Wr;
+        const float* wc = wl + co * 27;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = oy + 1 - ky;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xx = ox + 1 - kx;
+                if (xx < 0 || xx >= W) continue;
+                const float gv = gp[(size_t)(yy * r + si) * Wr + (xx * r + sj)];
+                a0 = fmaf(wc[ky * 3 + kx], gv, a0);
+                a1 = fmaf(wc[9 + ky * 3 + kx], gv, a1);
+                a2 = fmaf(wc[18 + ky * 3 + kx], gv, a2);
+            }
+        }
+    }
+    const size_t o = ((size_t)b * 3 * H + oy) * W + ox;
+    gx[o] = a0; gx[o + (size_t)H * W] = a1; gx[o + 2 * (size_t)H * W] = a2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of (antialiased resize -> clamp): gin[y][x] = sum over the output pixels whose taps cover
+// (y, x) of wy*wx*gout, gout masked by 0 <= pre <= 1 when `pre` (the pre-clamp output) is given.
+// oy0/oyn, ox0/oxn: for every input row / column the contiguous range of outputs that reference it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_aa_bwd_kernel(
+    const float* __restrict__ gout, const float* __restrict__ pre, float* __restrict__ gin,
+    const int* __restrict__ ymin, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
+    const float* __restrict__ xw, int KX, const int* __restrict__ oy0, const int* __restrict__ oyn,
+    const int* __restrict__ ox0, const int* __restrict__ oxn, int Hi, int Wi, int Ho, int Wo)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int plane = blockIdx.z;
+    if (x >= Wi || y >= Hi) return;
+    const float* go = gout + (size_t)plane * Ho * Wo;
+    const float* pr = pre ? pre + (size_t)plane * Ho * Wo : nullptr;
+    float acc = 0.f;
+    const int ya = oy0[y], yn = oyn[y], xa = ox0[x], xn = oxn[x];
+    for (int i = 0; i < yn; ++i) {
+        const int oy = ya + i;
+        const float wyv = yw[oy * KY + (y - ymin[oy])];
+        float h = 0.f;
+        for (int j = 0; j < xn; ++j) {
+            const int ox = xa + j;
+            float gv = go[(size_t)oy * Wo + ox];
+            if (pr) { const float pv = pr[(size_t)oy * Wo + ox]; if (!(pv >= 0.f && pv <= 1.f)) gv = 0.f; }
+            h = fmaf(xw[ox * KX + (x - xmin[ox])], gv, h);
+        }
+        acc = fmaf(wyv, h, acc);
+    }
+    gin[((size_t)plane * Hi + y) * Wi + x] = acc;
+}
+
+// gin = gout * (0 <= pre <= 1) [* (relu_src > 0)]
+__global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
+                                                       const float* __restrict__ relu_src, float* __restrict__ gin, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        float g = gout[i];
+        if (pre) { const float p = pre[i]; if (!(p >= 0.f && p <= 1.f)) g = 0.f; }
+        if (relu_src && !(relu_src[i] > 0.f)) g = 0.f;
+        gin[i] = g;
+    }
+}
+
+// out = (a + b + fold(gpe)) * (feat > 0): merges the three gradient paths into `feat` (skip add,
+// up-branch, patch_embed) and applies conv2's ReLU backward.  gpe is the reflect-PADDED map
+// [B][Hp][Wp][64]; rows/cols >= H/W fold back onto 2H-2-y / 2W-2-x (F.pad reflect backward).
+__global__ __launch_bounds__(256) void feat_grad_combine_kernel(
+    const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, const bf16_t* __restrict__ gpe,
+    const bf16_t* __restrict__ feat, bf16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp)
+{
+    const size_t total = (size_t)B * H * W * 8;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = idx & 7;
+        size_t pix = idx >> 3;
+        const int x = pix % W; pix /= W;
+        const int y = pix % H;
+        const int bb = pix / H;
+        const size_t off = (((size_t)bb * H + y) * W + x) * 64 + c * 8;
+        float v[8];
+        auto addv = [&](const bf16_t* p, bool first) {
+            const u32x4 w4 = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = __builtin_bit_cast(float, w4[q] << 16), hi = __builtin_bit_cast(float, w4[q] & 0xffff0000u);
+                if (first) { v[2 * q] = lo; v[2 * q + 1] = hi; } else { v[2 * q] += lo; v[2 * q + 1] += hi; }
+            }
+        };
+        addv(a + off, true);
+        if (b) addv(b + off, false);
+        const int y2 = 2 * H - 2 - y, x2 = 2 * W - 2 - x;
+        const bool fy = (y2 >= H && y2 < Hp), fx = (x2 >= W && x2 < Wp);
+        auto gpe_at = [&](int yy, int xx) { return gpe + (((size_t)bb * Hp + yy) * Wp + xx) * 64 + c * 8; };
+        addv(gpe_at(y, x), false);
+        if (fy) addv(gpe_at(y2, x), false);
+        if (fx) addv(gpe_at(y, x2), false);
+        if (fy && fx) addv(gpe_at(y2, x2), false);
+        const u32x4 f4 = *reinterpret_cast<const u32x4*>(feat + off);
+        uint32_t pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float flo = __builtin_bit_cast(float, f4[q] << 16), fhi = __builtin_bit_cast(float, f4[q] & 0xffff0000u);
+            pk[q] = pack_bf16x2(flo > 0.f ? v[2 * q] : 0.f, fhi > 0.f ? v[2 * q + 1] : 0.f);
+        }
+        *reinterpret_cast<u32x4*>(out + off) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+    }
+}
+
+int persistent_grid(long long ntiles, int per_cu) {
+    long long g = 256LL * per_cu;
+    return (int)(ntiles < g ? ntiles : g);
+}
+
+}  // namespace
+
+// dwp fp32 [64][9][64] (co, tap, ci) +=, dbias fp32 [64] += (or NULL).  x NHWC bf16 [B][H][W][64];
+// gmap NHWC bf16 [B][H*gr][W*gr][64], sub-pixel plane sp (gr = 1, sp = 0: plain).
+extern "C" int tup_conv3x3_c64_wgrad(const void* x, const void* gmap, float* dwp, float* dbias,
+                                     int B, int H, int W, int gr, int sp, void* stream)
+{
+    if (B <= 0) return 0;
+    if (gr < 1 || sp < 0 || sp >= gr * gr) return (int)hipErrorInvalidValue;
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    static bool attr_set = false;
+    const size_t lds = X_TILE_BYTES + 256 * 128;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, 2)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const bf16_t*)x, (const bf16_t*)gmap, dwp, dbias, B, H, W, gr, sp, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// thin conv (cout 3): gpl fp32 [B][3][H][W]; dwp fp32 [3][9][64] +=, dbias fp32 [3] += (or NULL).
+extern "C" int tup_conv3x3_thin_wgrad(const void* x, const float* gpl, float* dwp, float* dbias,
+                                      int B, int H, int W, void* stream)
+{
+    if (B <= 0) return 0;
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    conv3x3_wgrad_thin_kernel<<<dim3(persistent_grid(nt, 3)), dim3(256), X_TILE_BYTES + 3 * 256 * 4,
+                                reinterpret_cast<hipStream_t>(stream)>>>((const bf16_t*)x, gpl, dwp, dbias, B, H, W, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// conv1: x fp32 [B][3][H][W], gmap NHWC bf16 [B][H][W][64]; dw fp32 [64][3][3][3] +=, dbias [64] +=.
+extern "C" int tup_conv3x3_c3_wgrad(const float* x, const void* gmap, float* dw, float* dbias,
+                                    int B, int H, int W, void* stream)
+{
+    if (B <= 0) return 0;
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    conv3x3_wgrad_c3_kernel<<<dim3(persistent_grid(nt, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        x, (const bf16_t*)gmap, dw, dbias, B, H, W, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// planar convs: x fp32 [B][3][H][W]; gpl fp32 [B][3][H*r][W*r]; dw fp32 [3*r*r][3][3][3] +=, dbias [3*r*r] +=.
+extern "C" int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float* dw, float* dbias,
+                                        int B, int H, int W, int r, void* stream)
+{
+    if (B <= 0) return 0;
+    if (r < 1 || r > 6) return (int)hipErrorInvalidValue;
+    const int cout = 3 * r * r;
+    if (cout * 28 > 12 * 256) return (int)hipErrorInvalidValue;
+    const int th = (r >= 4) ? 2 : (r == 3 ? 4 : 8);
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + th - 1) / th;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const size_t lds = ((size_t)3 * (th + 2) * HALO_W + (size_t)cout * th * 32) * sizeof(float);
+    conv3x3_wgrad_planar_kernel<<<dim3(persistent_grid(nt, 4)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+        x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// gx fp32 [B][3][H][W] = dgrad of Conv2d(3, 3*r*r, 3)+PixelShuffle(r); gpl fp32 [B][3][H*r][W*r];
+// w fp32 [3*r*r][3][3][3] (reference layout, unpacked).
+extern "C" int tup_conv3x3_planar_dgrad(const float* gpl, const float* w, float* gx, int B, int H, int W, int r, void* stream)
+{
+    if (B <= 0) return 0;
+    if (r < 1 || r > 6 || B > 65535) return (int)hipErrorInvalidValue;
+    dim3 grid((W + 63) / 64, (H + 3) / 4, B);
+    conv3x3_dgrad_planar_kernel<<<grid, dim3(256), (size_t)3 * r * r * 27 * sizeof(float), reinterpret_cast<hipStream_t>(stream)>>>(
+        gpl, w, gx, H, W, r);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// gin fp32 [planes][Hi][Wi] (overwritten) = backward of resize (+ clamp mask from `pre`, may be NULL).
+extern "C" int tup_resize_aa_bwd(const float* gout, const float* pre, float* gin, const int* ymin, const float* yw, int KY,
+                                 const int* xmin, const float* xw, int KX, const int* oy0, const int* oyn,
+                                 const int* ox0, const int* oxn, int planes, int Hi, int Wi, int Ho, int Wo, void* stream)
+{
+    if (planes <= 0) return 0;
+    if (planes > 65535) return (int)hipErrorInvalidValue;
+    dim3 grid((Wi + 63) / 64, (Hi + 3) / 4, planes);
+    resize_aa_bwd_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// gin = gout * [0 <= pre <= 1] * [relu_src > 0]   (either mask source may be NULL)
+extern "C" int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, float* gin, long long n, void* stream)
+{
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    mask_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(gout, pre, relu_src, gin, (size_t)n);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// out = (a + b + fold_reflect(gpe)) * (feat > 0); all NHWC bf16, gpe is [B][ceil8(H)][ceil8(W)][64]; b may be NULL.
+extern "C" int tup_feat_grad_combine(const void* a, const void* b, const void* gpe, const void* feat, void* out,
+                                     int B, int H, int W, void* stream)
+{
+    if (B <= 0) return 0;
+    const int Hp = (H + 7) / 8 * 8, Wp = (W + 7) / 8 * 8;
+    long long blocks = ((long long)B * H * W * 8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    feat_grad_combine_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const bf16_t*)a, (const bf16_t*)b, (const bf16_t*)gpe, (const bf16_t*)feat, (bf16_t*)out, B, H, W, Hp, Wp);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

@@ -20,6 +20,7 @@ constexpr int ZERO_BASE = 3 * PLANE;                    // a zero plane for the 
 
 __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ in_mask, const bf16_t* __restrict__ out_mask,
     bf16_t* __restrict__ out, int H, int W, int relu, int tilesX, int tilesY)
 {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4 * PLANE];
@@ -36,8 +37,11 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
         const int yy = rem / LW, xx = rem - yy * LW;
         const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
         float v = 0.f;
-        if (c < 3 && xx < HALO_W && iy >= 0 && iy < H && ix >= 0 && ix < W)
-            v = x[(((size_t)b * 3 + c) * H + iy) * W + ix];
+        if (c < 3 && xx < HALO_W && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const size_t gi = (((size_t)b * 3 + c) * H + iy) * W + ix;
+            v = x[gi];
+            if (in_mask && !(in_mask[gi] > 0.f)) v = 0.f;      // ReLU backward fused into the load
+        }
         lds[idx] = f32_to_bf16(v);
     }
 
@@ -70,14 +74,26 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
         for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16x16x32(wf[ct], pf, f32x4{0.f, 0.f, 0.f, 0.f});
         if (oy >= H || ox >= W) continue;
         bf16_t* o = out + (((size_t)b * H + oy) * W + ox) * 64 + g * 16;
-        uint32_t pk[8];
+        uint32_t pk[8], mw[8];
+        if (out_mask) {
+            const bf16_t* mp = out_mask + (((size_t)b * H + oy) * W + ox) * 64 + g * 16;
+            const u32x4 m0 = *reinterpret_cast<const u32x4*>(mp), m1 = *reinterpret_cast<const u32x4*>(mp + 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = acc[ct][e] + bias[g * 16 + ct * 4 + e];
+                v[e] = acc[ct][e];
+                if (bias) v[e] += bias[g * 16 + ct * 4 + e];
                 if (relu) v[e] = fmaxf(v[e], 0.f);
+                if (out_mask) {
+                    const int wi = (ct * 4 + e) >> 1;
+                    const float mv = __builtin_bit_cast(float, (e & 1) ? (mw[wi] & 0xffff0000u) : (mw[wi] << 16));
+                    if (!(mv > 0.f)) v[e] = 0.f;
+                }
             }
             pk[ct * 2 + 0] = pack_bf16x2(v[0], v[1]);
             pk[ct * 2 + 1] = pack_bf16x2(v[2], v[3]);
@@ -172,16 +188,19 @@ __global__ __launch_bounds__(256) void clamp01_kernel(const float* __restrict__ 
 
 // x: [B][3][H][W] fp32 (NCHW, as the reference module receives it); wp: [64][32] bf16 packed
 // (row n_local = ct*16+4g+e holds channel g*16+ct*4+e; k = tap*3 + cin, zero padded 27..31);
-// bias: [64] fp32 in channel order; out: [B][H][W][64] bf16.
-extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* bias, void* out,
-                                  int B, int H, int W, int relu, void* stream)
+// bias: [64] fp32 in channel order (or NULL); out: [B][H][W][64] bf16.
+// The same kernel is the input-gradient conv of the 64->3 convs (up1_conv, decoder_conv2) with the
+// transposed/flipped weight packed as wp; for that use in_mask (fp32, shape of x: input *= in_mask > 0,
+// the ReLU backward of up1_conv) and out_mask (bf16 NHWC, shape of out: out *= out_mask > 0).
+extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* bias, const float* in_mask,
+                                  const void* out_mask, void* out, int B, int H, int W, int relu, void* stream)
 {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nblk = (long long)tilesX * tilesY * B;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     conv3x3_c3_kernel<<<dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, (const bf16_t*)wp, bias, (bf16_t*)out, H, W, relu, tilesX, tilesY);
+        x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -184,13 +184,24 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
         const int nb = n0 + g * 16;
 
         if constexpr (EPI == E_BF16 || EPI == E_GELU_BF16) {
-            uint32_t pk[8];
+            uint32_t pk[8], ppre[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 float a = v[2 * q], b = v[2 * q + 1];
                 if (p.bias) { a += p.bias[nb + 2 * q]; b += p.bias[nb + 2 * q + 1]; }
-                if constexpr (EPI == E_GELU_BF16) { a = gelu_erf(a); b = gelu_erf(b); }
+                if constexpr (EPI == E_GELU_BF16) {
+                    ppre[q] = pack_bf16x2(a, b);      // pre-activation, saved (bf16) by the training path
+                    a = gelu_erf(a);
+                    b = gelu_erf(b);
+                }
                 pk[q] = pack_bf16x2(a, b);
+            }
+            if constexpr (EPI == E_GELU_BF16) {
+                if (p.skip) {
+                    bf16_t* po = const_cast<bf16_t*>(p.skip) + (size_t)m * p.ldo + nb;
+                    *reinterpret_cast<u32x4*>(po) = u32x4{ppre[0], ppre[1], ppre[2], ppre[3]};
+                    *reinterpret_cast<u32x4*>(po + 8) = u32x4{ppre[4], ppre[5], ppre[6], ppre[7]};
+                }
             }
             bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
             *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
@@ -274,6 +285,7 @@ int launch(const GemmParams& p, hipStream_t s)
 
 // epilogue: 0 = (+bias) -> bf16, 1 = +bias, erf-GELU -> bf16, 2 = +bias +res(fp32) -> fp32,
 //           3 = * gelu'(aux) -> bf16 (aux = bf16 [M][ldo] pre-activation; backward of model.py:148).
+//           With epilogue 1 a non-NULL aux is an OUTPUT: the bf16 pre-activation is saved there.
 // a_dtype: 0 = bf16 A, 1 = fp32 A (converted to bf16 on the way into LDS).  bias may be NULL for 0 and 3.
 extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
                                    const float* res, const void* aux, void* out, int ldo, int M, int N, int K,

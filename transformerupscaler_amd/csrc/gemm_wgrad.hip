@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
 
 // column sums: out[n] += sum_m G[m][n]
 template <bool F32>
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, int ld, float* __restrict__ out, int M, int N, int mchunk)
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, int ld, float* __restrict__ out, int M, int N, int mchunk,
+                                                     const unsigned char* __restrict__ rowmask)
 {
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sub = threadIdx.x >> 6;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G,
     float s = 0.f;
     if (n < N)
         for (int m = mbeg + sub; m < mend; m += 4)
-            s += F32 ? ((const float*)G)[(size_t)m * ld + n] : bf16_to_f32(((const bf16_t*)G)[(size_t)m * ld + n]);
+            if (!rowmask || rowmask[m]) s += F32 ? ((const float*)G)[(size_t)m * ld + n] : bf16_to_f32(((const bf16_t*)G)[(size_t)m * ld + n]);
     __shared__ float red[4][64];
     red[sub][threadIdx.x & 63] = s;
     __syncthreads();
@@ -205,8 +206,9 @@ extern "C" int tup_patch_wgrad(const float* P, const void* map, float* out, int 
     return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
-// out[N] += column sums of G [M][N] (bias gradients).
-extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, void* stream)
+// out[N] += column sums of G [M][N] (bias gradients); rowmask (uint8 [M], may be NULL) selects the rows
+// that count (patch_embed's bias does not reach the zero-padded tokens).
+extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, const void* rowmask, void* stream)
 {
     if (M <= 0 || N <= 0) return 0;
     int msplit = 256;
@@ -215,8 +217,8 @@ extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, i
     msplit = (M + mchunk - 1) / mchunk;
     dim3 grid((N + 63) / 64, msplit);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == 1) colsum_kernel<true><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk);
-    else colsum_kernel<false><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk);
+    if (dtype == 1) colsum_kernel<true><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk, (const unsigned char*)rowmask);
+    else colsum_kernel<false><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk, (const unsigned char*)rowmask);
     TUP_CHECK_LAUNCH();
     return 0;
 }

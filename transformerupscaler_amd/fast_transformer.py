@@ -137,16 +137,21 @@ class TransformerModel(nn.Module):
     def _versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def packed(self, scale: int):
+    def packed(self, scale: int, backward: bool = False):
+        """Packed weights (+ dense relative-position biases) for `scale`; re-packed when any parameter
+        was updated in place (optimizer step) or moved."""
         ver = self._versions()
-        hit = self._pack_cache.get(scale)
-        if hit is not None and hit[0] == ver:
-            return hit[1], hit[2]
-        sd = {k: v for k, v in self.named_parameters()}
-        pk = packing.pack_state_dict(sd, scale)
-        frags = [ops.relpos_bias_expand(pk[f"b{i}.table"]) for i in range(len(self.window_blocks))]
-        self._pack_cache = {scale: (ver, pk, frags)}
-        return pk, frags
+        key = (scale, bool(backward))
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != ver:
+            sd = {k: v for k, v in self.named_parameters()}
+            pk = packing.pack_state_dict(sd, scale, backward=backward)
+            nb = len(self.window_blocks)
+            frags_t = [ops.relpos_bias_expand(pk[f"b{i}.table"]) for i in range(nb)]
+            frags_n = [ops.relpos_bias_expand_n(pk[f"b{i}.table"]) for i in range(nb)] if backward else None
+            hit = (ver, pk, frags_t, frags_n)
+            self._pack_cache = {key: hit}
+        return (hit[1], hit[2], hit[3]) if backward else (hit[1], hit[2])
 
     def forward(self, x: torch.Tensor, res_out: Tuple[int, int] = (1080, 1920), upscale_factor: Optional[int] = None,
                 require_ratio: bool = True) -> torch.Tensor:

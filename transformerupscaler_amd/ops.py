@@ -34,23 +34,28 @@ def _opt(t, dtype, shape, name):
     return None if t is None else _chk(t, dtype, shape, name)
 
 
-def conv1(x, wp, bias, relu=True):
+def conv1(x, wp, bias, relu=True, in_mask=None, out_mask=None):
+    """planar fp32 [B][3][H][W] -> NHWC bf16 64 ch (conv1; also the input-gradient conv of the 64->3 convs)."""
     B, C, H, W = x.shape
     assert C == 3
     out = torch.empty((B, H, W, 64), dtype=BF16, device=x.device)
     _lib.call("tup_conv3x3_c3_fwd", _chk(x, F32, None, "x"), _chk(wp, BF16, (64, 32), "wp"),
-              _chk(bias, F32, (64,), "bias"), out.data_ptr(), B, H, W, int(relu), _stream())
+              _opt(bias, F32, (64,), "bias"), _opt(in_mask, F32, x.shape, "in_mask"),
+              _opt(out_mask, BF16, out.shape, "out_mask"), out.data_ptr(), B, H, W, int(relu), _stream())
     return out
 
 
-def conv_c64(x, wp, bias, r=1, relu=False):
-    """NHWC bf16 conv 64 -> 64*r*r with fused PixelShuffle(r); returns [B][H*r][W*r][64] bf16."""
-    B, H, W, C = x.shape
-    assert C == 64
+def conv_c64(x, wp, bias, r=1, relu=False, add=None, mask=None, in_r=1):
+    """NHWC bf16 conv 64*in_r^2 -> 64*r*r with fused PixelShuffle(r); returns [B][H*r][W*r][64] bf16.
+    x is [B][H*in_r][W*in_r][64] (in_r > 1: channels read through PixelShuffle^-1)."""
+    B, Hi, Wi, C = x.shape
+    assert C == 64 and Hi % in_r == 0 and Wi % in_r == 0
+    H, W = Hi // in_r, Wi // in_r
     nt = r * r
     out = torch.empty((B, H * r, W * r, 64), dtype=BF16, device=x.device)
-    _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (nt, 9, 64, 64), "wp"),
-              _opt(bias, F32, (nt, 64), "bias"), out.data_ptr(), B, H, W, nt, r, 64, int(relu), 0, _stream())
+    _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (nt, in_r * in_r, 9, 64, 64), "wp"),
+              _opt(bias, F32, (nt, 64), "bias"), _opt(add, BF16, out.shape, "add"), _opt(mask, BF16, out.shape, "mask"),
+              out.data_ptr(), B, H, W, nt, r, 64, int(relu), 0, in_r, _stream())
     return out
 
 
@@ -59,8 +64,8 @@ def conv_c64_thin(x, wp, bias, cout, relu=False):
     B, H, W, C = x.shape
     assert C == 64 and 1 <= cout <= 16
     out = torch.empty((B, cout, H, W), dtype=F32, device=x.device)
-    _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (1, 9, 16, 64), "wp"),
-              _opt(bias, F32, (cout,), "bias"), out.data_ptr(), B, H, W, 1, 1, cout, int(relu), 1, _stream())
+    _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (1, 1, 9, 16, 64), "wp"),
+              _opt(bias, F32, (cout,), "bias"), None, None, out.data_ptr(), B, H, W, 1, 1, cout, int(relu), 1, 1, _stream())
     return out
 
 
@@ -135,7 +140,8 @@ def window_attn(qkv, bias_frag):
 
 
 def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None):
-    """epilogue 'bf16' | 'gelu' | 'res' (fp32 out = a@wt^T + bias + res) | 'gelu_bwd' (bf16 out = (a@wt^T) * gelu'(aux))."""
+    """epilogue 'bf16' | 'gelu' (aux, if given, receives the bf16 pre-activation) | 'res' (fp32 out = a@wt^T + bias
+    + res) | 'gelu_bwd' (bf16 out = (a@wt^T) * gelu'(aux))."""
     M, K = a.shape
     N = wt.shape[0]
     assert tuple(wt.shape) == (N, K) and N % 64 == 0 and K % 64 == 0
@@ -149,7 +155,7 @@ def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None):
         resp = _chk(res, F32, (M, N), "res")
     else:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
-        if epi == 3:
+        if epi == 3 or (epi == 1 and aux is not None):
             auxp = _chk(aux, BF16, (M, N), "aux")
     _lib.call("tup_gemm_tokens_fwd", _chk(a, a.dtype, None, "a"), a_dtype, K, _chk(wt, BF16, None, "wt"),
               _opt(bias, F32, (N,), "bias"), resp, auxp, out.data_ptr(), N, M, N, K, epi, _stream())
@@ -208,12 +214,12 @@ def patch_wgrad(p, fmap, reflect):
     return out
 
 
-def colsum(g, out=None):
+def colsum(g, out=None, rowmask=None):
     M, N = g.shape
     if out is None:
         out = torch.zeros((N,), dtype=F32, device=g.device)
     _lib.call("tup_colsum", _chk(g, g.dtype, None, "g"), {BF16: 0, F32: 1}[g.dtype], N, _chk(out, F32, (N,), "out"),
-              M, N, _stream())
+              M, N, _opt(rowmask, torch.uint8, (M,), "rowmask"), _stream())
     return out
 
 
@@ -263,3 +269,97 @@ def patch_embed_bwd(gx, wt, B, H, W):
     _lib.call("tup_patch_embed_bwd", _chk(gx, F32, (B * nwy * nwx * 64, 192), "gx"), _chk(wt, BF16, (4096, 192), "wt"),
               gmap.data_ptr(), B, H, W, _stream())
     return gmap
+
+
+def conv_c64_wgrad(x, gmap, gr=1):
+    """-> (dwp fp32 [gr*gr][64][9][64] (sp, co, tap, ci), dbias fp32 [gr*gr][64])."""
+    B, H, W, C = x.shape
+    assert C == 64 and tuple(gmap.shape) == (B, H * gr, W * gr, 64)
+    dwp = torch.zeros((gr * gr, 64, 9, 64), dtype=F32, device=x.device)
+    db = torch.zeros((gr * gr, 64), dtype=F32, device=x.device)
+    for sp in range(gr * gr):
+        _lib.call("tup_conv3x3_c64_wgrad", _chk(x, BF16, None, "x"), _chk(gmap, BF16, None, "gmap"), dwp[sp].data_ptr(),
+                  db[sp].data_ptr(), B, H, W, gr, sp, _stream())
+    return dwp, db
+
+
+def conv_thin_wgrad(x, gpl, want_bias):
+    B, H, W, C = x.shape
+    assert C == 64
+    dwp = torch.zeros((3, 9, 64), dtype=F32, device=x.device)
+    db = torch.zeros((3,), dtype=F32, device=x.device) if want_bias else None
+    _lib.call("tup_conv3x3_thin_wgrad", _chk(x, BF16, None, "x"), _chk(gpl, F32, (B, 3, H, W), "gpl"), dwp.data_ptr(),
+              None if db is None else db.data_ptr(), B, H, W, _stream())
+    return dwp, db
+
+
+def conv1_wgrad(x, gmap):
+    B, C, H, W = x.shape
+    assert C == 3
+    dw = torch.zeros((64, 3, 3, 3), dtype=F32, device=x.device)
+    db = torch.zeros((64,), dtype=F32, device=x.device)
+    _lib.call("tup_conv3x3_c3_wgrad", _chk(x, F32, None, "x"), _chk(gmap, BF16, (B, H, W, 64), "gmap"), dw.data_ptr(),
+              db.data_ptr(), B, H, W, _stream())
+    return dw, db
+
+
+def conv_planar_wgrad(x, gpl, r):
+    B, C, H, W = x.shape
+    cout = 3 * r * r
+    dw = torch.zeros((cout, 3, 3, 3), dtype=F32, device=x.device)
+    db = torch.zeros((cout,), dtype=F32, device=x.device)
+    _lib.call("tup_conv3x3_planar_wgrad", _chk(x, F32, None, "x"), _chk(gpl, F32, (B, 3, H * r, W * r), "gpl"),
+              dw.data_ptr(), db.data_ptr(), B, H, W, r, _stream())
+    return dw, db
+
+
+def conv_planar_dgrad(gpl, w, r):
+    B, C, Hr, Wr = gpl.shape
+    H, W = Hr // r, Wr // r
+    gx = torch.empty((B, 3, H, W), dtype=F32, device=gpl.device)
+    _lib.call("tup_conv3x3_planar_dgrad", _chk(gpl, F32, None, "gpl"), _chk(w, F32, (3 * r * r, 3, 3, 3), "w"),
+              gx.data_ptr(), B, H, W, r, _stream())
+    return gx
+
+
+_INV_CACHE = {}
+
+
+def _inv_taps_on(device, in_size, out_size):
+    key = (str(device), in_size, out_size)
+    if key not in _INV_CACHE:
+        from .resize_taps import aa_inverse_ranges
+        o0, on = aa_inverse_ranges(in_size, out_size)
+        _INV_CACHE[key] = (torch.from_numpy(o0).to(device), torch.from_numpy(on).to(device))
+    return _INV_CACHE[key]
+
+
+def resize_aa_bwd(gout, in_hw, pre=None):
+    """Backward of resize_aa (+clamp when `pre`, the pre-clamp output, is given)."""
+    B, C, Ho, Wo = gout.shape
+    Hi, Wi = in_hw
+    ylo, _, yw, ky = _taps_on(gout.device, Hi, Ho)
+    xlo, _, xw, kx = _taps_on(gout.device, Wi, Wo)
+    oy0, oyn = _inv_taps_on(gout.device, Hi, Ho)
+    ox0, oxn = _inv_taps_on(gout.device, Wi, Wo)
+    gin = torch.empty((B, C, Hi, Wi), dtype=F32, device=gout.device)
+    _lib.call("tup_resize_aa_bwd", _chk(gout, F32, None, "gout"), _opt(pre, F32, gout.shape, "pre"), gin.data_ptr(),
+              ylo.data_ptr(), yw.data_ptr(), ky, xlo.data_ptr(), xw.data_ptr(), kx, oy0.data_ptr(), oyn.data_ptr(),
+              ox0.data_ptr(), oxn.data_ptr(), B * C, Hi, Wi, Ho, Wo, _stream())
+    return gin
+
+
+def mask_bwd(gout, pre=None, relu_src=None):
+    gin = torch.empty_like(gout)
+    _lib.call("tup_mask_bwd", _chk(gout, F32, None, "gout"), _opt(pre, F32, gout.shape, "pre"),
+              _opt(relu_src, F32, gout.shape, "relu_src"), gin.data_ptr(), gout.numel(), _stream())
+    return gin
+
+
+def feat_grad_combine(a, b, gpe, feat):
+    B, H, W, C = feat.shape
+    hp, wp = (H + 7) // 8 * 8, (W + 7) // 8 * 8
+    out = torch.empty_like(feat)
+    _lib.call("tup_feat_grad_combine", _chk(a, BF16, feat.shape, "a"), _opt(b, BF16, feat.shape, "b"),
+              _chk(gpe, BF16, (B, hp, wp, 64), "gpe"), _chk(feat, BF16, None, "feat"), out.data_ptr(), B, H, W, _stream())
+    return out

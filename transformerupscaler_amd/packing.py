@@ -31,7 +31,7 @@ def pack_conv_c64(weight: torch.Tensor, bias, r: int):
     w = w.permute(1, 3, 0, 2)                            # [sp][tap][c][cin]
     w = w.index_select(2, _PERM64.to(w.device))          # row n_local <- channel perm[n_local]
     b = None if bias is None else bias.reshape(64, r * r).t().contiguous().float()
-    return w.contiguous().to(torch.bfloat16), b
+    return w.unsqueeze(1).contiguous().to(torch.bfloat16), b       # [ntile][in-chunk = 1][9][64][64]
 
 
 def pack_conv_c64_thin(weight: torch.Tensor):
@@ -40,7 +40,7 @@ def pack_conv_c64_thin(weight: torch.Tensor):
     assert weight.shape[1] == 64 and co <= 16
     w = torch.zeros(9, 16, 64, dtype=weight.dtype, device=weight.device)
     w[:, :co, :] = weight.reshape(co, 64, 9).permute(2, 0, 1)
-    return w.unsqueeze(0).contiguous().to(torch.bfloat16)
+    return w.view(1, 1, 9, 16, 64).contiguous().to(torch.bfloat16)
 
 
 def pack_conv1(weight: torch.Tensor):
@@ -75,8 +75,34 @@ def pack_patch_unembed(weight: torch.Tensor):
     return pack_linear(weight.permute(2, 3, 1, 0).reshape(4096, 192))
 
 
-def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int) -> Dict[str, torch.Tensor]:
-    """Everything one forward at `scale` needs, keyed by short names."""
+# ---- backward (input-gradient) packings: the same kernels run with transposed / flipped weights ----
+def pack_conv_c64_dgrad(weight: torch.Tensor, r: int):
+    """Conv2d(64, 64*r*r, 3) -> weights of its input-gradient conv (64*r*r -> 64, read through
+    PixelShuffle^-1): bf16 [1][r*r][9][64 rows = cin][64 = c]."""
+    w = weight.reshape(64, r * r, 64, 3, 3).flip(3, 4).reshape(64, r * r, 64, 9)    # [c][sp][cin][tap']
+    w = w.permute(1, 3, 2, 0)                                                       # [sp][tap'][cin][c]
+    w = w.index_select(2, _PERM64.to(w.device))
+    return w.unsqueeze(0).contiguous().to(torch.bfloat16)
+
+
+def pack_conv_thin_dgrad(weight: torch.Tensor):
+    """Conv2d(64, 3, 3) -> conv1-format weights (3 -> 64) of its input-gradient conv."""
+    return pack_conv1(weight.flip(2, 3).transpose(0, 1).contiguous())
+
+
+def pack_planar_dgrad(weight: torch.Tensor):
+    """Conv2d(3, 3, 3) -> planar weights of its input-gradient conv."""
+    return pack_planar(weight.flip(2, 3).transpose(0, 1).contiguous())
+
+
+def unpack_conv_c64_wgrad(dwp: torch.Tensor, db, r: int):
+    """[r*r][64 c][9][64 ci] (+ bias [r*r][64]) -> reference layout [64*r*r][64][3][3] (+ [64*r*r])."""
+    dw = dwp.permute(1, 0, 3, 2).reshape(64 * r * r, 64, 3, 3)
+    return dw, (None if db is None else db.t().reshape(-1))
+
+
+def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = False) -> Dict[str, torch.Tensor]:
+    """Everything one forward (and, with backward=True, one backward) at `scale` needs, keyed by short names."""
     pk: Dict[str, torch.Tensor] = {}
     f32 = lambda t: t.detach().float().contiguous()
     pk["conv1.w"] = pack_conv1(sd["conv1.weight"].detach()); pk["conv1.b"] = f32(sd["conv1.bias"])
@@ -100,4 +126,22 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int) -> Dict[str, torch.
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
     pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])
+    if not backward:
+        return pk
+    # ---- extra packings the backward needs ----
+    t = lambda k: sd[k].detach()
+    pk["conv2.wd"] = pack_conv_c64_dgrad(t("conv2.weight"), 1)
+    pk["dec1.wd"] = pack_conv_c64_dgrad(t("decoder_conv1.weight"), 1)
+    pk["dec2.wd"] = pack_conv_thin_dgrad(t("decoder_conv2.weight"))
+    pk["up1_conv.wd"] = pack_conv_thin_dgrad(t("up1_conv.conv.weight"))
+    pk["fuc.wd"] = pack_planar_dgrad(t("final_upscale_conv.weight"))
+    for si, (idx, r) in enumerate(upsampler_layout(scale)):
+        pk[f"up1.{si}.wd"] = pack_conv_c64_dgrad(t(f"up1.upsamplers.{scale}.{idx}.weight"), r)
+        pk[f"fu.{si}.raw"] = f32(sd[f"final_upscale.upsamplers.{scale}.{idx}.weight"])
+    pk["pe.wd"] = pack_linear(t("patch_embed.weight").permute(2, 3, 1, 0).reshape(4096, 192))     # rows (i,j,c), cols n
+    pk["pu.wd"] = pack_linear(t("patch_unembed.weight").permute(0, 2, 3, 1).reshape(192, 4096))   # rows k, cols (i,j,o)
+    for i in range(BLOCKS):
+        p = f"window_blocks.{i}"
+        for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
+            pk[f"b{i}.{nm}.wd"] = pack_linear(t(f"{p}.{key}.weight").t().contiguous())
     return pk

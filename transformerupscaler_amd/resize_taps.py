@@ -34,3 +34,23 @@ def aa_taps(in_size: int, out_size: int):
         tot = (tot + w[:, k]).astype(np.float32)
     w = np.where(tot[:, None] != 0, w / np.where(tot == 0, f(1.0), tot)[:, None], w).astype(np.float32)
     return lo.astype(np.int32), n, np.ascontiguousarray(w), kmax
+
+
+@functools.lru_cache(maxsize=64)
+def aa_inverse_ranges(in_size: int, out_size: int):
+    """For every input index the contiguous range [o0, o0+on) of output indices whose taps cover it
+    (the transpose of the forward table; used by the resize backward)."""
+    lo, n, _, _ = aa_taps(in_size, out_size)
+    o0 = np.full(in_size, out_size, np.int32)
+    o1 = np.zeros(in_size, np.int32)
+    for o in range(out_size):
+        a, b = int(lo[o]), int(lo[o] + n[o])
+        o0[a:b] = np.minimum(o0[a:b], o)
+        o1[a:b] = np.maximum(o1[a:b], o + 1)
+    on = np.maximum(o1 - o0, 0).astype(np.int32)
+    o0 = np.where(on > 0, o0, 0).astype(np.int32)
+    # contiguity check: every output in [o0, o0+on) must really cover the input index
+    for i in range(in_size):
+        for o in range(int(o0[i]), int(o0[i] + on[i])):
+            assert lo[o] <= i < lo[o] + n[o]
+    return o0, on

@@ -18,10 +18,8 @@ from .weights import BLOCKS, active_param_names, upsampler_layout
 
 BF16, F32 = torch.bfloat16, torch.float32
 
-# Optional hook for data-parallel training: called as grad_ready_hook(names: List[str], grads:
-# Dict[str, Tensor]) as soon as a group of parameter gradients is final, in reverse execution order,
-# so a reducer can start its all-reduce while the rest of the backward still runs (dp.py).
-grad_ready_hook: Optional[Callable[[List[str], Dict[str, torch.Tensor]], None]] = None
+# Data-parallel training (dp.py): a reducer attached to the module is told, in reverse execution order,
+# as soon as a group of parameter gradients is final, so its all-reduce overlaps the rest of the backward.
 
 _ROWMASK_CACHE = {}
 
@@ -85,13 +83,13 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio):
     return ops.clamp01(pre), sv
 
 
-def backward_train(pk, frags_t, frags_n, sv, scale, gout) -> Dict[str, torch.Tensor]:
+def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None) -> Dict[str, torch.Tensor]:
     """Returns {reference parameter name: gradient} for the parameters active at `scale`."""
     g: Dict[str, torch.Tensor] = {}
 
     def ready(*names):
-        if grad_ready_hook is not None:
-            grad_ready_hook(list(names), g)
+        if reducer is not None:
+            reducer.on_ready(list(names), g)
 
     x, feat, ui = sv["x"], sv["feat"], sv["ui"]
     B, _, H, W = x.shape
@@ -199,12 +197,15 @@ class _FastTransformerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout)
+        reducer = getattr(ctx.module, "_grad_reducer", None)
+        grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout, reducer)
+        if reducer is not None:
+            grads = reducer.finish()          # averaged over ranks (views of the flat bucket buffer)
         ctx.sv = None
         outs = []
         for n in ctx.names:
             gr = grads.get(n)
-            outs.append(None if gr is None else gr.contiguous())
+            outs.append(None if gr is None else gr.contiguous().clone() if reducer is not None else gr.contiguous())
         return (None, None, None, None, None, None) + tuple(outs)
 
 

@@ -1,0 +1,36 @@
+"""Training-step harness with the semantics of the reference loop (train.py:110-146): zero_grad,
+forward with ``res_out = HR size, require_ratio=False``, antialiased Resize to the HR size when shapes
+differ, L1 loss, backward, Adam step.  Equal-shaped samples are batched (the reference loops over
+samples at B=1; mean of per-sample L1 means == batch L1 mean for equal shapes)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .autograd import resize_aa
+
+
+def make_optimizer(model, lr: float = 1e-4):
+    """train.py:104 -- Adam, default betas/eps, no weight decay (parameters without grad are skipped)."""
+    return torch.optim.Adam(model.parameters(), lr=lr)
+
+
+def train_step(model, optimizer, lr_batch: torch.Tensor, hr_batch: torch.Tensor) -> torch.Tensor:
+    optimizer.zero_grad(set_to_none=True)                                    # train.py:113
+    out = model(lr_batch, res_out=tuple(hr_batch.shape[2:]), require_ratio=False)      # train.py:124
+    if tuple(out.shape[2:]) != tuple(hr_batch.shape[2:]):
+        out = resize_aa(out, tuple(hr_batch.shape[2:]))                      # train.py:127-130
+    loss = F.l1_loss(out, hr_batch)                                          # train.py:103,132,136
+    loss.backward()                                                          # train.py:138 (bf16 needs no GradScaler)
+    optimizer.step()                                                         # train.py:139
+    return loss.detach()
+
+
+def save_checkpoint(model, checkpoint_dir: str, epoch: int) -> str:
+    """train.py:152-156: weights only, ``model_epoch_{n}.pth``."""
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    path = os.path.join(checkpoint_dir, f"model_epoch_{epoch}.pth")
+    torch.save(model.state_dict(), path)
+    return path

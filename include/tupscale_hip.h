@@ -48,6 +48,15 @@ int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* bias, const 
                         const void* mask, void* out, int B, int H, int W, int ntiles, int r,
                         int cout_valid, int relu, int out_mode, int in_r, void* stream);
 
+/* Inference-only composition of branch A: the LAST Upsampler conv (64->64rr, +bias) + PixelShuffle(r)
+ * (utils.py:62-63,74-75,83-84) and up1_conv (64->3, no bias, ReLU; utils.py:32-40), called back to back at
+ * model.py:264-265 with no non-linearity between them, evaluated as one 5x5-tap conv with 3rr outputs
+ * (exact algebra; the outermost HR pixel ring uses per-border weight variants because the reference
+ * zero-pads the HR intermediate).  x bf16 NHWC [B][H][W][64]; wp bf16 [25][rows][64] (rows 16/32/112 for
+ * r 2/3/6); bias fp32 [3rr]; wv bf16 [9][3rr][25][64]; bv fp32 [9][3rr]; out fp32 [B][3][H*r][W*r]. */
+int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const float* bias, const void* wv,
+                               const float* bv, float* out, int B, int H, int W, int r, int relu, void* stream);
+
 /* Planar fp32 Conv2d(3, 3*r*r, k3, p1) + PixelShuffle(r) [+ add] [+ clamp(0,1)]:
  *   final_upscale utils.py:62-63,74-75,83-84 (n_feats=3) | final_upscale_conv model.py:212,317
  *   fused with "out = upscaled_input + residual_up" model.py:320 and torch.clamp model.py:327.

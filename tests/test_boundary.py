@@ -121,3 +121,29 @@ def test_resize_taps_match_oracle_and_aten():
         lo2, n2, w2 = O.aa_bilinear_taps(i, o)
         assert (lo == lo2).all() and (n == n2).all() and k == w2.shape[1]
         assert abs(w - w2).max() == 0.0
+
+
+@pytest.mark.parametrize("r", [2, 3])
+def test_branch_a_composition_is_exact(r):
+    """compose_branch_a (fp32, CPU) == Conv(64->64rr)+PixelShuffle+Conv(64->3) incl. the border variants."""
+    from transformerupscaler_amd import packing
+    g = torch.Generator().manual_seed(r)
+    H, W = 6, 7
+    feat = torch.rand((1, 64, H, W), generator=g)
+    wu, bu = torch.rand((64 * r * r, 64, 3, 3), generator=g) - 0.5, torch.rand((64 * r * r,), generator=g)
+    w3 = torch.rand((3, 64, 3, 3), generator=g) - 0.5
+    ref = F.conv2d(F.pixel_shuffle(F.conv2d(feat, wu, bu, padding=1), r), w3, None, padding=1)
+    fp = F.pad(feat, (2, 2, 2, 2))
+    out = torch.zeros_like(ref)
+    Hs, Ws = H * r, W * r
+    for Y in range(Hs):
+        for X in range(Ws):
+            rm = 1 if Y == 0 else (2 if Y == Hs - 1 else 0)
+            cm = 1 if X == 0 else (2 if X == Ws - 1 else 0)
+            wc, bc = packing.compose_branch_a(wu, bu, w3, r, rm, cm)
+            y, si, x, sj = Y // r, Y % r, X // r, X % r
+            win = fp[0, :, y:y + 5, x:x + 5].permute(1, 2, 0)            # [5][5][64]
+            for c in range(3):
+                n = c * r * r + si * r + sj
+                out[0, c, Y, X] = (wc[n] * win).sum() + bc[n]
+    assert (out - ref).abs().max() < 2e-4

@@ -60,7 +60,7 @@ def test_intermediates_vs_oracle(model, det_sd):
     with torch.no_grad():
         O.forward(det_sd, x, upscale_factor=2, capture=cap_o)
         pk, frags = model.packed(2)
-        engine.forward(pk, frags, x.cuda(), 2, (136, 168), True, capture=cap_h)
+        engine.forward(pk, frags, x.cuda(), 2, (136, 168), True, capture=cap_h, fuse_branch_a=False)
     nhwc = lambda t: t.permute(0, 2, 3, 1)
     checks = [("feat", nhwc(cap_o["feat"]), 3e-2), ("up1", nhwc(cap_o["up1"]), 3e-2),
               ("upscaled_input", cap_o["upscaled_input"], 3e-2), ("win_in", cap_o["win_in"].reshape(-1, 192), 2e-2),
@@ -71,6 +71,29 @@ def test_intermediates_vs_oracle(model, det_sd):
         err = (got - ref).abs().max().item()
         rel = err / max(ref.abs().max().item(), 1e-6)
         assert rel <= tol, f"{name}: max abs {err:.4f} rel {rel:.4f}"
+
+
+@pytest.mark.parametrize("scale,shape", [(2, (2, 3, 68, 84)), (3, (1, 3, 20, 28)), (4, (1, 3, 20, 28)), (6, (1, 3, 20, 28)), (2, (1, 3, 8, 32))])
+def test_composed_branch_a_matches_explicit(model, det_sd, scale, shape):
+    """The inference-only composition (last up-conv + PixelShuffle + up1_conv as one 5x5 conv) against the
+    oracle's explicit chain, incl. the HR border ring, and against the explicit HIP kernels."""
+    from transformerupscaler_amd import engine
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(scale))
+    cap_o, cap_c, cap_e = {}, {}, {}
+    with torch.no_grad():
+        O.forward(det_sd, x, upscale_factor=scale, capture=cap_o)
+        pk, frags = model.packed(scale)
+        res = (shape[2] * scale, shape[3] * scale)
+        engine.forward(pk, frags, x.cuda(), scale, res, True, capture=cap_c, fuse_branch_a=True)
+        engine.forward(pk, frags, x.cuda(), scale, res, True, capture=cap_e, fuse_branch_a=False)
+    ref = cap_o["upscaled_input"]
+    got_c, got_e = cap_c["upscaled_input"].cpu(), cap_e["upscaled_input"].cpu()
+    tol = 1.2e-2 * max(1.0, ref.abs().max().item())
+    assert (got_c - ref).abs().max().item() <= tol, (got_c - ref).abs().max().item()
+    ring = torch.ones_like(ref, dtype=torch.bool); ring[..., 1:-1, 1:-1] = False
+    assert (got_c - ref)[ring].abs().max().item() <= tol          # border ring uses the weight variants
+    # the composition skips the bf16 rounding of the HR intermediate, so it is at least as close as the explicit path
+    assert (got_c - ref).abs().mean().item() <= (got_e - ref).abs().mean().item() * 1.1 + 1e-5
 
 
 def test_unbuilt_scale_and_cpu_inputs_raise(model):

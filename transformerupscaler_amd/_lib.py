@@ -21,6 +21,7 @@ SIGNATURES = {
     "tup_abi_version": [],
     "tup_conv3x3_c3_fwd": [P, P, P, P, P, P, I, I, I, I, P],
     "tup_conv3x3_c64_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
+    "tup_conv5x5_c64_planar_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "tup_conv3x3_planar_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "tup_resize_aa_fwd": [P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P],
     "tup_clamp01_fwd": [P, P, c_longlong, P],

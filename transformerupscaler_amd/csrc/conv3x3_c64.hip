@@ -15,24 +15,27 @@
 // MFMA operands: A = weights (rows = cout), B = pixels (cols), v_mfma_f32_16x16x32_bf16,
 // so a lane ends up with 16 consecutive output channels of one pixel (32-B stores).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int TH = 8, TW = 32, HALO_W = TW + 2, HALO_H = TH + 2, NPIX_HALO = HALO_H * HALO_W;
-constexpr int IN_TILE_BYTES = NPIX_HALO * 128;
+constexpr int TH = 8, TW = 32;
+constexpr int in_tile_bytes(int ks) { return (TH + ks - 1) * (TW + ks - 1) * 128; }
 
 enum { OUT_NHWC_BF16 = 0, OUT_PLANAR_F32 = 1 };
 
-template <int CT, int OUT_MODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
+template <int CT, int OUT_MODE, int KS>
+__global__ __launch_bounds__(256, (CT <= 4 && KS == 3) ? 2 : 1) void conv3x3_c64_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ add, const bf16_t* __restrict__ mask,
     void* __restrict__ out, int H, int W, int ntiles, int r, int cout_valid, int relu,
     int tilesX, int tilesY, int in_r)
 {
+    constexpr int PADK = KS / 2, HALO_W = TW + KS - 1, HALO_H = TH + KS - 1, NPIX_HALO = HALO_H * HALO_W;
+    constexpr int NTAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* in_lds = smem;
-    char* w_lds = smem + IN_TILE_BYTES;
+    char* w_lds = smem + in_tile_bytes(KS);
     constexpr int WROWS = CT * 16;            // weight rows per (ntile, tap) slab
     constexpr int WSLAB = WROWS * 128;        // bytes
     constexpr int WCH = WROWS * 8;            // 16-byte chunks per slab
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
         for (int idx = tid; idx < NPIX_HALO * 8; idx += 256) {
             const int q = idx >> 3, c = idx & 7;
             const int yy = q / HALO_W, xx = q - yy * HALO_W;
-            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+            const int iy = ty0 - PADK + yy, ix = tx0 - PADK + xx;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (iy >= 0 && iy < H && ix >= 0 && ix < W)
                 v = *reinterpret_cast<const u32x4*>(xb + ((size_t)(iy * in_r + si) * Win + (ix * in_r + sj)) * 64 + c * 8);
@@ -87,14 +90,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
 #pragma unroll
     for (int pg = 0; pg < 4; ++pg) qb[pg] = (2 * wave + (pg >> 1)) * HALO_W + (pg & 1) * 16 + p;
 
-    f32x4 acc[4][CT];
-    const int total = ntiles * nci * 9;
+    f32x4 acc[4][CT], bv[CT];
+    const int total = ntiles * nci * NTAPS;
     wload(0);
     wstore(0);
     __syncthreads();
 
     for (int it = 0; it < total; ++it) {
-        const int tap = it % 9, chunk_it = it / 9;
+        const int tap = it % NTAPS, chunk_it = it / NTAPS;
         const int ci = chunk_it % nci, nt = chunk_it / nci;
         const int buf = it & 1;
         if (tap == 0 && it > 0 && nci > 1) {      // next input-channel chunk (all waves are past the last barrier)
@@ -107,8 +110,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
             for (int pg = 0; pg < 4; ++pg)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {       // bias of this lane's channels, one vector load per cout tile
+                bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (bias) {
+                    if constexpr (OUT_MODE == OUT_NHWC_BF16) bv[ct] = *reinterpret_cast<const f32x4*>(bias + nt * 64 + g * 16 + ct * 4);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const int co = 16 * ct + 4 * g + e; bv[ct][e] = co < cout_valid ? bias[co] : 0.f; }
+                    }
+                }
+            }
         }
-        const int dy = tap / 3, dx = tap - dy * 3;
+        const int dy = tap / KS, dx = tap - dy * KS;
         const int qoff = dy * HALO_W + dx;
         const char* wb = w_lds + buf * WSLAB;
 #pragma unroll
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
         if (it + 1 < total) wstore(buf ^ 1);
         __syncthreads();
 
-        if (tap == 8 && ci == nci - 1) {
+        if (tap == NTAPS - 1 && ci == nci - 1) {
             // ---- epilogue for cout tile nt ----
 #pragma unroll
             for (int pg = 0; pg < 4; ++pg) {
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             v[e] = acc[pg][ct][e];
-                            if (bias) v[e] += bias[nt * 64 + g * 16 + ct * 4 + e];
+                            v[e] += bv[ct][e];
                             if (relu) v[e] = fmaxf(v[e], 0.f);
                             const int wi = (ct * 4 + e) >> 1;
                             if (add) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
@@ -179,21 +193,318 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(
                         *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                     }
                 } else {
-                    // thin output: rows 4g+reg are the real couts (< cout_valid); fp32 planar NCHW
+                    // thin output: rows 16ct+4g+reg are the real couts (< cout_valid); fp32 planar NCHW, written
+                    // through PixelShuffle(r): cout n = c*r*r + si*r + sj -> out[b][c][oy*r+si][ox*r+sj]
                     float* o = reinterpret_cast<float*>(out);
+                    const int rr = r * r, cimg = cout_valid / rr, Hr = H * r, Wr = W * r;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int co = 4 * g + e;
-                        if (co < cout_valid) {
-                            float v = acc[pg][0][e];
-                            if (bias) v += bias[co];
-                            if (relu) v = fmaxf(v, 0.f);
-                            o[(((size_t)b * cout_valid + co) * H + oy) * W + ox] = v;
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = 16 * ct + 4 * g + e;
+                            if (co < cout_valid) {
+                                float v = acc[pg][ct][e];
+                                v += bv[ct][e];
+                                if (relu) v = fmaxf(v, 0.f);
+                                const int c = co / rr, sp = co - c * rr;
+                                const int si = sp / r, sj = sp - si * r;
+                                o[(((size_t)b * cimg + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] = v;
+                            }
                         }
-                    }
                 }
             }
         }
+    }
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant (single input chunk, in_r = 1): one workgroup per CU walks the pixel tiles.
+//   * all NTAPS weight slabs of the current cout tile stay resident in LDS (73.7 KB for 3x3 / 64 couts),
+//     so a tile is NTAPS*2 MFMA K-steps with no barrier in between;
+//   * the next tile's halo image is fetched with LDS-DMA (global_load_lds_dwordx4, per-lane source
+//     address carries the XOR swizzle and the halo clipping; out-of-image lanes read a zero line)
+//     into the second input buffer while the current tile computes: one barrier per tile.
+// LDS: 9*8 KB + 2*43.5 KB = 160,768 B of the CU's 163,840 B.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int tup_zero_line[4] = {0u, 0u, 0u, 0u};
+
+TUP_DEVICE uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(p);
+}
+// ds_read the compiler does not track: the caller owns the wait (lds_wait) before the first use.
+TUP_DEVICE bf16x8 lds_read_b128_asm(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> TUP_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int CT, int OUT_MODE, int KS>
+__global__ __launch_bounds__(256, 1) void conv_c64_persistent_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const bf16_t* __restrict__ add, const bf16_t* __restrict__ mask,
+    void* __restrict__ out, int B, int H, int W, int ntiles, int r, int cout_valid, int relu,
+    int tilesX, int tilesY)
+{
+    constexpr int PADK = KS / 2, HALO_W = TW + KS - 1, HALO_H = TH + KS - 1, NPIX_HALO = HALO_H * HALO_W;
+    constexpr int NTAPS = KS * KS;
+    constexpr int IN_BYTES = NPIX_HALO * 128, IN_CHUNKS = NPIX_HALO * 8;
+    constexpr int WROWS = CT * 16, WSLAB = WROWS * 128, WCHUNKS = NTAPS * WROWS * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w_lds = smem;                              // [NTAPS][WROWS][128 B]
+    char* in_lds = smem + NTAPS * WSLAB;             // [2][IN_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    const int total_tiles = tilesX * tilesY * B;
+
+    auto prefetch_tile = [&](int tile, int buf) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        const bf16_t* xb = x + (size_t)b * H * W * 64;
+        char* dst = in_lds + buf * IN_BYTES;
+#pragma unroll 1
+        for (int base = 0; base < IN_CHUNKS; base += 256) {
+            const int idx = base + tid;                     // physical 16-B chunk of the LDS image
+            if (idx < IN_CHUNKS) {
+                const int q = idx >> 3, cphys = idx & 7;
+                const int c = cphys ^ ((q >> 1) & 7);       // logical chunk stored there (swizzle on the SOURCE side)
+                const int yy = q / HALO_W, xx = q - yy * HALO_W;
+                const int iy = ty0 - PADK + yy, ix = tx0 - PADK + xx;
+                const void* src = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                      ? (const void*)(xb + ((size_t)iy * W + ix) * 64 + c * 8) : (const void*)tup_zero_line;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + (base + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
+    auto stage_weights = [&](int nt) {
+        const bf16_t* wsrc = wp + (size_t)nt * NTAPS * WROWS * 64;
+        for (int idx = tid; idx < WCHUNKS; idx += 256) {
+            const int row = idx >> 3, c = idx & 7;             // row = tap*WROWS + n_local
+            *reinterpret_cast<u32x4*>(w_lds + swz128(row, c)) = *reinterpret_cast<const u32x4*>(wsrc + (size_t)idx * 8);
+        }
+    };
+
+    int qb[4];
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) qb[pg] = (2 * wave + (pg >> 1)) * HALO_W + (pg & 1) * 16 + p;
+
+    // loop-invariant LDS byte offsets of this lane's fragments (kh = 0): pixel fragments per (tap, pixel group)
+    // relative to the input buffer, weight fragments relative to slab row 0
+    uint32_t poff[NTAPS][4];
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap)
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) poff[tap][pg] = (uint32_t)swz128(qb[pg] + (tap / KS) * HALO_W + (tap % KS), g);
+    const uint32_t wbase = lds_addr(w_lds) + (uint32_t)swz128(p, g);
+
+    int buf = 0;
+    if ((int)blockIdx.x < total_tiles) prefetch_tile(blockIdx.x, 0);
+    for (int nt = 0; nt < ntiles; ++nt) {
+        stage_weights(nt);
+        // bias of this lane's output channels, loaded once per cout tile (an ordinary load issued while an
+        // LDS-DMA is in flight makes hipcc wait vmcnt(0) right there -- 16 of them per pixel group in the
+        // epilogue cost more than the whole K loop)
+        f32x4 bv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                if constexpr (OUT_MODE == OUT_NHWC_BF16) bv[ct] = *reinterpret_cast<const f32x4*>(bias + nt * 64 + g * 16 + ct * 4);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const int co = 16 * ct + 4 * g + e; bv[ct][e] = co < cout_valid ? bias[co] : 0.f; }
+                }
+            }
+        }
+        __syncthreads();            // weights visible; the compiler's vmcnt(0) here also retires the pending tile DMA
+        for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+            // next tile of this pass, or the first tile of the next pass (input tiles do not depend on nt)
+            int nxt = tile + gridDim.x;
+            if (nxt >= total_tiles) nxt = (nt + 1 < ntiles) ? (int)blockIdx.x : -1;
+            if (nxt >= 0) prefetch_tile(nxt, buf ^ 1);
+
+            f32x4 acc[4][CT];
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // K loop: NTAPS*2 steps of 32 channels, software-pipelined by hand: the fragments of step k+1 are
+            // requested before the MFMAs of step k issue (one wave per SIMD: nothing else hides LDS latency).
+            // The reads are inline-asm ds_read_b128 with a hand-counted s_waitcnt lgkmcnt(4+CT): hipcc's own
+            // waitcnt pass only ever emits lgkmcnt(0) here (it sinks reads to their first use otherwise), which
+            // would drain the reads just issued.  sched_barrier(0) keeps the MFMAs below the wait (guide 5.4 r18).
+            constexpr int NSTEPS = NTAPS * 2;
+            const uint32_t ibase = lds_addr(in_lds) + buf * IN_BYTES;
+            bf16x8 pf[2][4], wf[2][CT];
+            auto load_frags = [&](int step, int slot) {
+                const int tap = step >> 1;
+                const uint32_t khx = (step & 1) << 6;              // kh toggles chunk bit 2 = byte-offset bit 6
+#pragma unroll
+                for (int pg = 0; pg < 4; ++pg) pf[slot][pg] = lds_read_b128_asm(ibase + (poff[tap][pg] ^ khx));
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) wf[slot][ct] = lds_read_b128_asm((wbase ^ khx) + (tap * WROWS + ct * 16) * 128);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int step = 0; step < NSTEPS; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < NSTEPS) {
+                    load_frags(step + 1, cur ^ 1);
+                    lds_wait<4 + CT>();                            // step k's fragments have landed
+                } else {
+                    lds_wait<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = mfma16x16x32(wf[cur][ct], pf[cur][pg], acc[pg][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // ---- epilogue (same formats as conv3x3_c64_kernel) ----
+            int t = tile;
+            const int tx = t % tilesX; t /= tilesX;
+            const int ty = t % tilesY;
+            const int b = t / tilesY;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) {
+                const int oy = ty * TH + 2 * wave + (pg >> 1);
+                const int ox = tx * TW + (pg & 1) * 16 + p;
+                if (oy >= H || ox >= W) continue;
+                if constexpr (OUT_MODE == OUT_NHWC_BF16) {
+                    const int si = nt / r, sj = nt - si * r;
+                    const int Hr = H * r, Wr = W * r;
+                    const size_t eoff = (((size_t)b * Hr + (oy * r + si)) * Wr + (ox * r + sj)) * 64 + g * 16;
+                    uint32_t pk[8], aw[8], mw[8];
+                    if (add) {
+                        const u32x4 a0 = *reinterpret_cast<const u32x4*>(add + eoff), a1 = *reinterpret_cast<const u32x4*>(add + eoff + 8);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { aw[q] = a0[q]; aw[4 + q] = a1[q]; }
+                    }
+                    if (mask) {
+                        const u32x4 m0 = *reinterpret_cast<const u32x4*>(mask + eoff), m1 = *reinterpret_cast<const u32x4*>(mask + eoff + 8);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[pg][ct][e];
+                            v[e] += bv[ct][e];
+                            if (relu) v[e] = fmaxf(v[e], 0.f);
+                            const int wi = (ct * 4 + e) >> 1;
+                            if (add) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
+                            if (mask) {
+                                const float mv = __builtin_bit_cast(float, (e & 1) ? (mw[wi] & 0xffff0000u) : (mw[wi] << 16));
+                                if (!(mv > 0.f)) v[e] = 0.f;
+                            }
+                        }
+                        pk[ct * 2 + 0] = pack_bf16x2(v[0], v[1]);
+                        pk[ct * 2 + 1] = pack_bf16x2(v[2], v[3]);
+                    }
+                    if constexpr (CT == 4) {
+                        bf16_t* o = reinterpret_cast<bf16_t*>(out) + eoff;
+                        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+                    }
+                } else {
+                    float* o = reinterpret_cast<float*>(out);
+                    const int rr = r * r, cimg = cout_valid / rr, Hr = H * r, Wr = W * r;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int co = 16 * ct + 4 * g + e;
+                            if (co < cout_valid) {
+                                float v = acc[pg][ct][e];
+                                v += bv[ct][e];
+                                if (relu) v = fmaxf(v, 0.f);
+                                const int c = co / rr, sp = co - c * rr;
+                                const int si = sp / r, sj = sp - si * r;
+                                o[(((size_t)b * cimg + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] = v;
+                            }
+                        }
+                }
+            }
+            __syncthreads();        // (+ vmcnt(0)) next tile's DMA has landed, everyone is done reading `buf`
+            buf ^= 1;
+        }
+    }
+}
+
+template <int CT, int OUT_MODE, int KS>
+int launch_persistent(const void* x, const void* wp, const float* bias, const void* add, const void* mask, void* out,
+                      int B, int H, int W, int ntiles, int r, int cout_valid, int relu, hipStream_t s)
+{
+    constexpr int NPIX_HALO = (TH + KS - 1) * (TW + KS - 1);
+    constexpr size_t lds = (size_t)KS * KS * CT * 16 * 128 + 2 * (size_t)NPIX_HALO * 128;
+    static_assert(lds <= 163840, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_c64_persistent_kernel<CT, OUT_MODE, KS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
+    conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(256), lds, s>>>(
+        (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, B, H, W, ntiles, r,
+        cout_valid, relu, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Border fix-up of the composed branch-A conv (see tup_conv5x5_c64_planar_fwd): one wave per HR border
+// pixel recomputes it with the weight variant that leaves out the 64->3 conv's taps falling outside
+// the HR image (those see zero padding in the reference, not a virtual up-conv value).
+__global__ __launch_bounds__(256) void conv5x5_border_fix_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ wv, const float* __restrict__ bv,
+    float* __restrict__ out, int B, int H, int W, int r, int relu)
+{
+    const int lane = threadIdx.x & 63;
+    const int Hs = H * r, Ws = W * r, rr = r * r, nout = 3 * rr;
+    const int per_img = 2 * Ws + 2 * (Hs - 2);
+    const long long gid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gid >= (long long)per_img * B) return;
+    const int b = (int)(gid / per_img);
+    int k = (int)(gid - (long long)b * per_img);
+    int Y, X;
+    if (k < Ws) { Y = 0; X = k; }
+    else if (k < 2 * Ws) { Y = Hs - 1; X = k - Ws; }
+    else { k -= 2 * Ws; Y = 1 + (k >> 1); X = (k & 1) ? Ws - 1 : 0; }
+    const int rowmode = (Y == 0) ? 1 : (Y == Hs - 1 ? 2 : 0), colmode = (X == 0) ? 1 : (X == Ws - 1 ? 2 : 0);
+    const int v = rowmode * 3 + colmode;
+    const int y = Y / r, si = Y - y * r, xx0 = X / r, sj = X - xx0 * r;
+    const int sp = si * r + sj;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int tap = 0; tap < 25; ++tap) {
+        const int iy = y + tap / 5 - 2, ix = xx0 + tap % 5 - 2;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const float f = bf16_to_f32(x[(((size_t)b * H + iy) * W + ix) * 64 + lane]);
+        const bf16_t* wb = wv + (((size_t)v * nout) * 25 + tap) * 64 + lane;      // [v][n][tap][ci]
+        a0 = fmaf(f, bf16_to_f32(wb[(size_t)(0 * rr + sp) * 25 * 64]), a0);
+        a1 = fmaf(f, bf16_to_f32(wb[(size_t)(1 * rr + sp) * 25 * 64]), a1);
+        a2 = fmaf(f, bf16_to_f32(wb[(size_t)(2 * rr + sp) * 25 * 64]), a2);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+    if (lane < 3) {
+        float val = (lane == 0 ? a0 : (lane == 1 ? a1 : a2)) + bv[v * nout + lane * rr + sp];
+        if (relu) val = fmaxf(val, 0.f);
+        out[(((size_t)b * 3 + lane) * Hs + Y) * Ws + X] = val;
     }
 }
 
@@ -215,21 +526,83 @@ extern "C" int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* b
     const long long nblk = (long long)tilesX * tilesY * B;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool use_persistent = (getenv("TUP_CONV_NONPERSISTENT") == nullptr);
+    if (in_r == 1 && use_persistent) {
+        if (out_mode == OUT_NHWC_BF16) {
+            if (ntiles != r * r || r < 1) return (int)hipErrorInvalidValue;
+            return launch_persistent<4, OUT_NHWC_BF16, 3>(x, wp, bias, add, mask, out, B, H, W, ntiles, r, 64, relu, s);
+        }
+        if (out_mode == OUT_PLANAR_F32) {
+            if (ntiles != 1 || r != 1 || cout_valid < 1 || cout_valid > 16 || add || mask) return (int)hipErrorInvalidValue;
+            return launch_persistent<1, OUT_PLANAR_F32, 3>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, 1, cout_valid, relu, s);
+        }
+        return (int)hipErrorInvalidValue;
+    }
     if (out_mode == OUT_NHWC_BF16) {
         if (ntiles != r * r || r < 1) return (int)hipErrorInvalidValue;
-        const size_t lds = IN_TILE_BYTES + 2 * 64 * 128;
-        conv3x3_c64_kernel<4, OUT_NHWC_BF16><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
+        const size_t lds = in_tile_bytes(3) + 2 * 64 * 128;
+        conv3x3_c64_kernel<4, OUT_NHWC_BF16, 3><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
             (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, H, W, ntiles, r,
             64, relu, tilesX, tilesY, in_r);
     } else if (out_mode == OUT_PLANAR_F32) {
         if (ntiles != 1 || r != 1 || cout_valid < 1 || cout_valid > 16 || add || mask) return (int)hipErrorInvalidValue;
-        const size_t lds = IN_TILE_BYTES + 2 * 16 * 128;
-        conv3x3_c64_kernel<1, OUT_PLANAR_F32><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
+        const size_t lds = in_tile_bytes(3) + 2 * 16 * 128;
+        conv3x3_c64_kernel<1, OUT_PLANAR_F32, 3><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
             (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, 1, cout_valid, relu, tilesX,
             tilesY, in_r);
     } else {
         return (int)hipErrorInvalidValue;
     }
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Composed branch A for inference: Upsampler's last conv (64 -> 64*r*r, +bias), PixelShuffle(r) and
+// up1_conv (64 -> 3, no bias, ReLU) (reference utils.py:62-63,74-75,83-84 + utils.py:32-40, called at
+// model.py:264-265) have no non-linearity between them, so they are ONE linear map from the 64-channel LR
+// map to the 3-channel HR image: a 5x5 (LR taps) conv with 3*r*r outputs written through PixelShuffle.
+// K = 25*64 = 1600 and N = 3*r*r replace K = 576, N = 64*r*r followed by an HR 64->3 conv (12x fewer
+// FLOPs at r = 2) and the 64-channel HR tensor never exists.  Exactness: the composition is exact in
+// real arithmetic except on the outermost HR pixel ring, where the reference zero-pads the HR
+// intermediate; those pixels are recomputed with per-border weight variants (wv/bv).
+// x bf16 NHWC [B][H][W][64]; wp bf16 [25][rows][64] (rows = 16/32/112 for r = 2/3/6, row n = c*r*r+si*r+sj);
+// bias fp32 [3rr]; wv bf16 [9][3rr][25][64], bv fp32 [9][3rr] (variant = rowmode*3+colmode, mode 0 interior,
+// 1 first row/col, 2 last row/col); out fp32 [B][3][H*r][W*r].
+extern "C" int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const float* bias, const void* wv,
+                                          const float* bv, float* out, int B, int H, int W, int r, int relu,
+                                          void* stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (!(r == 2 || r == 3 || r == 6)) return (int)hipErrorInvalidValue;
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long nblk = (long long)tilesX * tilesY * B;
+    if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nout = 3 * r * r;
+    static const bool use_persistent5 = (getenv("TUP_CONV_NONPERSISTENT") == nullptr);
+    if (r == 2 && use_persistent5) {
+        int e = launch_persistent<1, OUT_PLANAR_F32, 5>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, r, nout, relu, s);
+        if (e) return e;
+    } else if (r == 2) {
+        conv3x3_c64_kernel<1, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), in_tile_bytes(5) + 2 * 16 * 128, s>>>(
+            (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, r, nout, relu, tilesX, tilesY, 1);
+    } else if (r == 3) {
+        static bool set3 = false;
+        const size_t lds = in_tile_bytes(5) + 2 * 32 * 128;
+        if (!set3) { hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<2, OUT_PLANAR_F32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set3 = true; }
+        conv3x3_c64_kernel<2, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
+            (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, r, nout, relu, tilesX, tilesY, 1);
+    } else {
+        static bool set6 = false;
+        const size_t lds = in_tile_bytes(5) + 2 * 112 * 128;
+        if (!set6) { hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<7, OUT_PLANAR_F32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set6 = true; }
+        conv3x3_c64_kernel<7, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
+            (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, r, nout, relu, tilesX, tilesY, 1);
+    }
+    TUP_CHECK_LAUNCH();
+    const long long nborder = (long long)B * (2LL * W * r + 2LL * (H * r - 2));
+    conv5x5_border_fix_kernel<<<dim3((unsigned)((nborder + 3) / 4)), dim3(256), 0, s>>>(
+        (const bf16_t*)x, (const bf16_t*)wv, bv, out, B, H, W, r, relu);
     TUP_CHECK_LAUNCH();
     return 0;
 }

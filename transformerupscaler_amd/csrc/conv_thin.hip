@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) wf[ct] = *reinterpret_cast<const bf16x8*>(wp + (ct * 16 + p) * 32 + 8 * g);
 
+    f32x4 bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias ? *reinterpret_cast<const f32x4*>(bias + g * 16 + ct * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+
     // im2col offsets of this lane group's 8 k values: k = tap*3 + c
     int koff[8];
 #pragma unroll
@@ -86,8 +90,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                v[e] = acc[ct][e];
-                if (bias) v[e] += bias[g * 16 + ct * 4 + e];
+                v[e] = acc[ct][e] + bv[ct][e];
                 if (relu) v[e] = fmaxf(v[e], 0.f);
                 if (out_mask) {
                     const int wi = (ct * 4 + e) >> 1;

@@ -172,6 +172,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
     }
 
     // ---- epilogue: lane holds features n0 + g*16 + ct*4 + e of token row m ----
+    float bvec[16];
+    {
+        const int bb = (EPI == E_UNEMBED) ? g * 16 : n0 + g * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) t = *reinterpret_cast<const f32x4*>(p.bias + bb + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bvec[4 * q + e] = t[e];
+        }
+    }
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
         const int m = m0 + 32 * wave + 16 * tg + pl;
@@ -187,8 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
             uint32_t pk[8], ppre[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                float a = v[2 * q], b = v[2 * q + 1];
-                if (p.bias) { a += p.bias[nb + 2 * q]; b += p.bias[nb + 2 * q + 1]; }
+                float a = v[2 * q] + bvec[2 * q], b = v[2 * q + 1] + bvec[2 * q + 1];
                 if constexpr (EPI == E_GELU_BF16) {
                     ppre[q] = pack_bf16x2(a, b);      // pre-activation, saved (bf16) by the training path
                     a = gelu_erf(a);
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
                 const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + 4 * q);
                 f32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = v[4 * q + e] + p.bias[nb + 4 * q + e] + rv[e];
+                for (int e = 0; e < 4; ++e) ov[e] = v[4 * q + e] + bvec[4 * q + e] + rv[e];
                 *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
             }
         } else if constexpr (EPI == E_PATCH_EMBED) {
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
             for (int q = 0; q < 4; ++q) {
                 f32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + (p.bias ? p.bias[nb + 4 * q + e] : 0.f) : 0.f;
+                for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + bvec[4 * q + e] : 0.f;
                 *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
             }
         } else if constexpr (EPI == E_GELU_BWD) {
@@ -259,8 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
                 const uint32_t sw = (q < 4) ? s0[q & 3] : s1[q & 3];
                 const float sa = __builtin_bit_cast(float, sw << 16);
                 const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
-                const float ba = p.bias ? p.bias[g * 16 + 2 * q] : 0.f, bb = p.bias ? p.bias[g * 16 + 2 * q + 1] : 0.f;
-                pk[q] = pack_bf16x2(v[2 * q] + ba + sa, v[2 * q + 1] + bb + sb);
+                pk[q] = pack_bf16x2(v[2 * q] + bvec[2 * q] + sa, v[2 * q + 1] + bvec[2 * q + 1] + sb);
             }
             bf16_t* o = (bf16_t*)p.out + off;
             *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};

@@ -60,21 +60,32 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
 
 
 def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int, res_out: Tuple[int, int],
-            require_ratio: bool = True, capture: Optional[dict] = None) -> torch.Tensor:
+            require_ratio: bool = True, capture: Optional[dict] = None, fuse_branch_a: bool = True) -> torch.Tensor:
     cap = capture
     x = x.contiguous().float()
     B, _, H, W = x.shape
     feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
-    feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+    with _stage("conv2"):
+        feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
     del feat1
     # branch A: Upsampler + up1_conv (conv, no bias, ReLU)
+    stages = upsampler_layout(scale)
     up = feat
-    for si, (_, r) in enumerate(upsampler_layout(scale)):
-        with _stage(f"up1.{si}"):
+    if fuse_branch_a and "bra.w" in pk:
+        # all but the last stage explicitly; the last conv + PixelShuffle + up1_conv as one composed 5x5 conv
+        for si, (_, r) in enumerate(stages[:-1]):
             up = ops.conv_c64(up, pk[f"up1.{si}.w"], pk[f"up1.{si}.b"], r, relu=False)
-    upscaled_input = ops.conv_c64_thin(up, pk["up1_conv.w"], None, 3, relu=True)
+        with _stage("branch_a"):
+            upscaled_input = ops.branch_a_composed(up, pk["bra.w"], pk["bra.b"], pk["bra.wv"], pk["bra.bv"], stages[-1][1])
+    else:
+        for si, (_, r) in enumerate(stages):
+            with _stage(f"up1.{si}"):
+                up = ops.conv_c64(up, pk[f"up1.{si}.w"], pk[f"up1.{si}.b"], r, relu=False)
+        upscaled_input = ops.conv_c64_thin(up, pk["up1_conv.w"], None, 3, relu=True)
+        if cap is not None:
+            cap["up1"] = up
     if cap is not None:
-        cap["feat"] = feat; cap["up1"] = up; cap["upscaled_input"] = upscaled_input
+        cap["feat"] = feat; cap["upscaled_input"] = upscaled_input
     del up
     # branch B: tokens
     xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])

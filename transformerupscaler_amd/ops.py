@@ -69,6 +69,18 @@ def conv_c64_thin(x, wp, bias, cout, relu=False):
     return out
 
 
+def branch_a_composed(x, wp, bias, wv, bv, r, relu=True):
+    """Composed (last up-conv + PixelShuffle + up1_conv [+ReLU]) 5x5 conv: NHWC bf16 [B][H][W][64] -> fp32 [B][3][H*r][W*r]."""
+    B, H, W, C = x.shape
+    assert C == 64 and r in (2, 3, 6)
+    rows, n = {2: 16, 3: 32, 6: 112}[r], 3 * r * r
+    out = torch.empty((B, 3, H * r, W * r), dtype=F32, device=x.device)
+    _lib.call("tup_conv5x5_c64_planar_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (1, 1, 25, rows, 64), "wp"),
+              _chk(bias, F32, (n,), "bias"), _chk(wv, BF16, (9, n, 25, 64), "wv"), _chk(bv, F32, (9, n), "bv"),
+              out.data_ptr(), B, H, W, r, int(relu), _stream())
+    return out
+
+
 def conv_planar(x, w28, bias, r=1, add=None, clamp=False):
     B, C, H, W = x.shape
     assert C == 3

@@ -75,6 +75,50 @@ def pack_patch_unembed(weight: torch.Tensor):
     return pack_linear(weight.permute(2, 3, 1, 0).reshape(4096, 192))
 
 
+# ---- composed branch A (inference): last Upsampler conv + PixelShuffle + up1_conv as one 5x5 conv ----
+def compose_branch_a(wu: torch.Tensor, bu: torch.Tensor, w3: torch.Tensor, r: int, rowmode: int = 0, colmode: int = 0):
+    """Exact composition (fp32) of Conv2d(64, 64*r*r, 3)+bias -> PixelShuffle(r) -> Conv2d(64, 3, 3, bias=False)
+    (utils.py:62-63/74-75/83-84 followed by utils.py:32-40; no activation in between, utils.py:50).
+    Returns (wc [3*r*r][5][5][64] with output n = c*r*r + si*r + sj and LR taps at offsets -2..2, bc [3*r*r]).
+    rowmode/colmode 1 (2) drop the HR taps above (below) / left (right) of the output pixel: the variants
+    for the first (last) HR row / column, where the reference zero-pads the HR intermediate."""
+    wu5 = wu.float().reshape(64, r, r, 64, 3, 3)          # [ch][si'][sj'][ci][ky][kx]
+    bu3 = bu.float().reshape(64, r, r)
+    w3 = w3.float()
+    wc = torch.zeros(3, r, r, 5, 5, 64, dtype=torch.float32, device=wu.device)
+    bc = torch.zeros(3, r, r, dtype=torch.float32, device=wu.device)
+    for si in range(r):
+        for dy in range(3):
+            if (rowmode == 1 and dy == 0) or (rowmode == 2 and dy == 2):
+                continue
+            oy, si2 = divmod(si + dy - 1, r)               # LR row offset and sub-row of the HR intermediate
+            for sj in range(r):
+                for dx in range(3):
+                    if (colmode == 1 and dx == 0) or (colmode == 2 and dx == 2):
+                        continue
+                    ox, sj2 = divmod(sj + dx - 1, r)
+                    m = torch.einsum("ch,hikl->cikl", w3[:, :, dy, dx], wu5[:, si2, sj2])     # [3][ci][ky][kx]
+                    wc[:, si, sj, oy + 1:oy + 4, ox + 1:ox + 4, :] += m.permute(0, 2, 3, 1)
+                    bc[:, si, sj] += w3[:, :, dy, dx] @ bu3[:, si2, sj2]
+    return wc.reshape(3 * r * r, 5, 5, 64), bc.reshape(3 * r * r)
+
+
+def pack_branch_a(wu, bu, w3, r: int):
+    """-> (wp bf16 [1][1][25][rows][64], bias fp32 [3rr], wv bf16 [9][3rr][25][64], bv fp32 [9][3rr])."""
+    rows = {2: 16, 3: 32, 6: 112}[r]
+    n = 3 * r * r
+    wc, bc = compose_branch_a(wu, bu, w3, r)
+    wp = torch.zeros(25, rows, 64, dtype=torch.float32, device=wu.device)
+    wp[:, :n, :] = wc.reshape(n, 25, 64).permute(1, 0, 2)
+    wv, bv = [], []
+    for rowmode in range(3):
+        for colmode in range(3):
+            a, b = compose_branch_a(wu, bu, w3, r, rowmode, colmode)
+            wv.append(a.reshape(n, 25, 64)); bv.append(b)
+    return (wp.view(1, 1, 25, rows, 64).contiguous().to(torch.bfloat16), bc.contiguous(),
+            torch.stack(wv).contiguous().to(torch.bfloat16), torch.stack(bv).contiguous())
+
+
 # ---- backward (input-gradient) packings: the same kernels run with transposed / flipped weights ----
 def pack_conv_c64_dgrad(weight: torch.Tensor, r: int):
     """Conv2d(64, 64*r*r, 3) -> weights of its input-gradient conv (64*r*r -> 64, read through
@@ -113,6 +157,11 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         k = f"final_upscale.upsamplers.{scale}.{idx}"
         pk[f"fu.{si}.w"] = pack_planar(sd[k + ".weight"].detach()); pk[f"fu.{si}.b"] = f32(sd[k + ".bias"])
     pk["up1_conv.w"] = pack_conv_c64_thin(sd["up1_conv.conv.weight"].detach())
+    if not backward:      # inference: composed branch A (last up stage + up1_conv)
+        idx, r = upsampler_layout(scale)[-1]
+        k = f"up1.upsamplers.{scale}.{idx}"
+        pk["bra.w"], pk["bra.b"], pk["bra.wv"], pk["bra.bv"] = pack_branch_a(
+            sd[k + ".weight"].detach(), sd[k + ".bias"].detach(), sd["up1_conv.conv.weight"].detach(), r)
     pk["fuc.w"] = pack_planar(sd["final_upscale_conv.weight"].detach()); pk["fuc.b"] = f32(sd["final_upscale_conv.bias"])
     pk["pe.w"] = pack_patch_embed(sd["patch_embed.weight"].detach()); pk["pe.b"] = f32(sd["patch_embed.bias"])
     for i in range(BLOCKS):

@@ -112,23 +112,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // thin convs (cout = 3: up1_conv, decoder_conv2): G planar fp32 [B][3][H][W], X NHWC bf16.
-// dwp[co][tap][ci] += ..., dbias[co] += sum G.  VALU: thread = (ci, tap group), persistent over tiles.
+// dwp[co][tap][ci] += ..., dbias[co] += sum G.  Same MFMA scheme as the 64-cout kernel with the 3 real
+// couts padded to one 16-row tile; the four waves split the 9 taps instead of the cout tiles.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv3x3_wgrad_thin_kernel(
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dwp, float* __restrict__ dbias,
     int B, int H, int W, int tilesX, int tilesY)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* x_lds = smem;
-    float* g_lds = reinterpret_cast<float*>(smem + X_TILE_BYTES);     // [3][256]
-    const int tid = threadIdx.x, ci = tid & 63, tg = tid >> 6;
-    const int tap0 = (tg == 0) ? 0 : 1 + 2 * tg, ntap = (tg == 0) ? 3 : 2;     // {0,1,2},{3,4},{5,6},{7,8}
-    float acc[3][3];
+    bf16_t* g_lds = reinterpret_cast<bf16_t*>(smem + X_TILE_BYTES);     // [256 pixels][16 couts] (3 real)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int trq = l16 >> 2, trp = l16 & 3;
+    const int ntap = (wave == 0) ? 3 : 2;                  // taps {0,4,8}, {1,5}, {2,6}, {3,7}
+    f32x4 acc[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[a][c] = 0.f;
-    float bsum = 0.f;
+        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[3] = {0.f, 0.f, 0.f};
+    for (int i = tid; i < 256 * 16; i += 256) g_lds[i] = f32_to_bf16(0.f);       // columns 3..15 stay zero
     const int ntiles = tilesX * tilesY * B;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
@@ -137,36 +141,59 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_thin_kernel(
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
         stage_x_halo(x_lds, x + (size_t)b * H * W * 64, H, W, ty0, tx0, tid);
-        for (int idx = tid; idx < 3 * 256; idx += 256) {
-            const int co = idx >> 8, pix = idx & 255;
-            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
-            g_lds[idx] = (oy < H && ox < W) ? gpl[(((size_t)b * 3 + co) * H + oy) * W + ox] : 0.f;
+        {
+            const int oy = ty0 + (tid >> 5), ox = tx0 + (tid & 31);
+            const bool ok = oy < H && ox < W;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                const float v = ok ? gpl[(((size_t)b * 3 + co) * H + oy) * W + ox] : 0.f;
+                bsum[co] += v;
+                g_lds[tid * 16 + co] = f32_to_bf16(v);
+            }
         }
         __syncthreads();
-        for (int pix = 0; pix < 256; ++pix) {
-            const float g0 = g_lds[pix], g1 = g_lds[256 + pix], g2 = g_lds[512 + pix];
-            const int qb = (pix >> 5) * HALO_W + (pix & 31);
+#pragma unroll 1
+        for (int ks = 0; ks < 16; ++ks) {
+            const int ry = ks >> 1, x0 = (ks & 1) * 16;
+            const int gp = ry * 32 + x0 + 4 * g + trq;
+            const s16x4 af = lds_read_tr16(reinterpret_cast<const char*>(g_lds) + gp * 32 + trp * 8);
+            const int qbase = ry * HALO_W + x0 + 4 * g + trq;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 if (a < ntap) {
-                    const int tap = tap0 + a;
-                    const int q = qb + (tap / 3) * HALO_W + (tap % 3);
-                    const float xv = bf16_to_f32(*reinterpret_cast<const bf16_t*>(x_lds + swz128(q, ci >> 3) + (ci & 7) * 2));
-                    acc[a][0] = fmaf(g0, xv, acc[a][0]);
-                    acc[a][1] = fmaf(g1, xv, acc[a][1]);
-                    acc[a][2] = fmaf(g2, xv, acc[a][2]);
+                    const int tap = wave + 4 * a;
+                    const int q = qbase + (tap / 3) * HALO_W + (tap % 3);
+#pragma unroll
+                    for (int cit = 0; cit < 4; ++cit) {
+                        const int xcol = 16 * cit + 4 * trp;
+                        const s16x4 bfr = lds_read_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2);
+                        acc[a][cit] = mfma16x16x16(af, bfr, acc[a][cit]);
+                    }
                 }
             }
-            if (tid < 3) bsum += g_lds[tid * 256 + pix];
         }
         __syncthreads();
     }
+    // D[row = co 4g+e][col = ci l16]: only rows 0..2 (g == 0, e < 3) are real
+    if (g == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-        if (a < ntap)
+        for (int a = 0; a < 3; ++a)
+            if (a < ntap)
 #pragma unroll
-            for (int co = 0; co < 3; ++co) atomicAdd(dwp + ((size_t)co * 9 + tap0 + a) * 64 + ci, acc[a][co]);
-    if (dbias && tid < 3) atomicAdd(dbias + tid, bsum);
+                for (int cit = 0; cit < 4; ++cit)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e)
+                        atomicAdd(dwp + ((size_t)e * 9 + wave + 4 * a) * 64 + 16 * cit + l16, acc[a][cit][e]);
+    }
+    if (dbias) {
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            float v = bsum[co];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) atomicAdd(dbias + co, v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,7 +500,7 @@ extern "C" int tup_conv3x3_thin_wgrad(const void* x, const float* gpl, float* dw
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    conv3x3_wgrad_thin_kernel<<<dim3(persistent_grid(nt, 3)), dim3(256), X_TILE_BYTES + 3 * 256 * 4,
+    conv3x3_wgrad_thin_kernel<<<dim3(persistent_grid(nt, 2)), dim3(256), X_TILE_BYTES + 256 * 32,
                                 reinterpret_cast<hipStream_t>(stream)>>>((const bf16_t*)x, gpl, dwp, dbias, B, H, W, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     return 0;

@@ -141,22 +141,45 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
             atomicAdd(p.out + (size_t)(i0 + 16 * wave + 4 * g + e) * p.ldo + j0 + 16 * jt + l16, acc[jt][e]);
 }
 
-// column sums: out[n] += sum_m G[m][n]
+// column sums: out[n] += sum_m G[m][n].  16-byte loads: LPR lanes cover a 64-column stripe of one row, the
+// block's other lanes take further rows; grid.x = column stripes, grid.y splits M.
 template <bool F32>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G, int ld, float* __restrict__ out, int M, int N, int mchunk,
                                                      const unsigned char* __restrict__ rowmask)
 {
-    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sub = threadIdx.x >> 6;
+    constexpr int EPL = F32 ? 4 : 8;            // elements per lane per load
+    constexpr int LPR = 64 / EPL;               // lanes per row stripe
+    constexpr int RPB = 256 / LPR;              // rows per block iteration
+    const int lc = threadIdx.x % LPR, lr = threadIdx.x / LPR;
+    const int n = blockIdx.x * 64 + lc * EPL;
     const int mbeg = blockIdx.y * mchunk, mend = min(M, mbeg + mchunk);
-    float s = 0.f;
-    if (n < N)
-        for (int m = mbeg + sub; m < mend; m += 4)
-            if (!rowmask || rowmask[m]) s += F32 ? ((const float*)G)[(size_t)m * ld + n] : bf16_to_f32(((const bf16_t*)G)[(size_t)m * ld + n]);
-    __shared__ float red[4][64];
-    red[sub][threadIdx.x & 63] = s;
+    float acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int m = mbeg + lr; m < mend; m += RPB) {
+        if (rowmask && !rowmask[m]) continue;
+        if constexpr (F32) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)G + (size_t)m * ld + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        } else {
+            const u32x4 v = *reinterpret_cast<const u32x4*>((const bf16_t*)G + (size_t)m * ld + n);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[2 * q] += __builtin_bit_cast(float, v[q] << 16);
+                acc[2 * q + 1] += __builtin_bit_cast(float, v[q] & 0xffff0000u);
+            }
+        }
+    }
+    __shared__ float red[RPB][64 + 1];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) red[lr][lc * EPL + e] = acc[e];
     __syncthreads();
-    if (sub == 0 && n < N) atomicAdd(out + n, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int r = 0; r < RPB; ++r) s += red[r][threadIdx.x];
+        atomicAdd(out + blockIdx.x * 64 + threadIdx.x, s);
+    }
 }
 
 template <int PMODE, int QMODE>
@@ -211,11 +234,13 @@ extern "C" int tup_patch_wgrad(const float* P, const void* map, float* out, int 
 extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, const void* rowmask, void* stream)
 {
     if (M <= 0 || N <= 0) return 0;
-    int msplit = 256;
+    if (N % 64 != 0 || ld % 8 != 0) return (int)hipErrorInvalidValue;
+    int msplit = 2048 / (N / 64);
+    if (msplit < 1) msplit = 1;
     int mchunk = (M + msplit - 1) / msplit;
-    if (mchunk < 64) mchunk = 64;
+    if (mchunk < 256) mchunk = 256;
     msplit = (M + mchunk - 1) / mchunk;
-    dim3 grid((N + 63) / 64, msplit);
+    dim3 grid(N / 64, msplit);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == 1) colsum_kernel<true><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk, (const unsigned char*)rowmask);
     else colsum_kernel<false><<<grid, dim3(256), 0, s>>>(G, ld, out, M, N, mchunk, (const unsigned char*)rowmask);

@@ -83,8 +83,10 @@ int tup_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
 int tup_relpos_bias_expand(const float* table, float* frag, void* stream);
 
 /* WindowAttention core model.py:114-130 (q*scale, qk^T + bias, softmax, @v, head concat).
- * qkv bf16 [nwin][64][576]; out bf16 [nwin][64][192]. */
-int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, void* stream);
+ * qkv bf16 [nwin][64][576]; out bf16 [nwin][64][192].  drop_p > 0: attn_drop (model.py:80,127) with a
+ * stateless hash mask keyed by drop_seed (csrc/common.h); the backward re-derives the same mask. */
+int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, float drop_p,
+                        unsigned int drop_seed, void* stream);
 
 /* nn.Linear family model.py:79,81,146-151 with fused epilogues (forward AND the input-gradient
  * GEMMs of the backward, which are the same product with the transposed weight packed as Wt).
@@ -92,10 +94,11 @@ int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int 
  * a_dtype 0: A bf16 [M][lda]; 1: A fp32.  epilogue 0: (+bias) -> bf16 | 1: +bias, erf-GELU -> bf16
  * (model.py:148) | 2: +bias + res -> fp32 (residual adds model.py:164,171) | 3: * gelu'(aux) -> bf16
  * (aux bf16 [M][ldo] = saved pre-activation; backward of model.py:148).  With epilogue 1 a non-NULL
- * aux is an OUTPUT that receives the bf16 pre-activation (saved for the backward). */
+ * aux is an OUTPUT that receives the bf16 pre-activation (saved for the backward).  drop_p > 0 (epilogue 2):
+ * out = dropout(acc + bias) + res -- proj_drop / the MLP's Dropout (model.py:82,132,150). */
 int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
                         const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
-                        int epilogue, void* stream);
+                        int epilogue, float drop_p, unsigned int drop_seed, void* stream);
 
 /* reflect pad + patch_embed Conv2d(64,192,k8,s8) + NHWC permute + zero token pad +
  * window_partition: model.py:256-261,268-285.  feat bf16 NHWC; Wt bf16 [192][4096],
@@ -137,7 +140,10 @@ int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream);
 
 /* Attention-core backward (recomputes P): gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] +=. */
 int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                        void* gqkv, float* dbias_t, int nwin, void* stream);
+                        void* gqkv, float* dbias_t, int nwin, float drop_p, unsigned int drop_seed, void* stream);
+
+/* Backward of nn.Dropout after proj / mlp.2: gout bf16 = gin fp32 * mask / (1 - p), element index m*192+n. */
+int tup_dropout_bwd(const float* gin, void* gout, long long n, float drop_p, unsigned int drop_seed, void* stream);
 
 /* dense bias gradient -> relative_position_bias_table.grad fp32 [225][12] (overwritten). */
 int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream);

@@ -7,14 +7,16 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_int, c_longlong, c_void_p
+from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtupscale_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 P = c_void_p
 I = c_int
+F = c_float
+U = c_uint
 
 # name -> argtypes, mirrors include/tupscale_hip.h one to one
 SIGNATURES = {
@@ -27,8 +29,8 @@ SIGNATURES = {
     "tup_clamp01_fwd": [P, P, c_longlong, P],
     "tup_layernorm_fwd": [P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand": [P, P, P],
-    "tup_window_attn_fwd": [P, P, P, I, P],
-    "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, P, I, I, I, I, I, P],
+    "tup_window_attn_fwd": [P, P, P, I, F, U, P],
+    "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "tup_patch_embed_fwd": [P, P, P, P, I, I, I, P],
     "tup_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
     # backward
@@ -37,7 +39,8 @@ SIGNATURES = {
     "tup_colsum": [P, I, I, P, I, I, P, P],
     "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand_n": [P, P, P],
-    "tup_window_attn_bwd": [P, P, P, P, P, P, I, P],
+    "tup_window_attn_bwd": [P, P, P, P, P, P, I, F, U, P],
+    "tup_dropout_bwd": [P, P, c_longlong, F, U, P],
     "tup_relpos_bias_reduce": [P, P, P],
     "tup_patch_unembed_bwd": [P, P, P, I, I, I, P],
     "tup_patch_embed_bwd": [P, P, P, I, I, I, P],

@@ -4,8 +4,9 @@ Replaces what torch autograd does for reference models/FastTransformer/model.py:
 train.py:113-140: every gradient below is produced by a HIP kernel through the C ABI (ops.py); torch
 only carries the node in its graph, owns the tensors and accumulates ``.grad``.
 
-Dropout (model.py:80-82,127,132,150; p = 0.1 in ``.train()`` mode) is not applied on this path yet:
-the graph is the eval-mode graph, which is also what the parity fixtures use.
+Dropout (model.py:80-82,127,132,150; p = 0.1) is applied in ``.train()`` mode with stateless hash masks that
+the backward re-derives (nothing is stored); ``.eval()`` with grads enabled gives the dropout-free graph the
+parity fixtures use.  The masks are not torch's Philox stream -- same distribution, different bits.
 """
 from __future__ import annotations
 
@@ -35,9 +36,15 @@ def _valid_token_rowmask(B, H, W, device):
     return _ROWMASK_CACHE[key]
 
 
-def forward_train(pk, frags_t, x, scale, res_out, require_ratio):
-    """Same stages as engine.forward, keeping what the backward needs in `sv`."""
-    sv = {}
+def site_seed(seed: int, block: int, site: int) -> int:
+    """Per-dropout-site seed (site 0 = attn_drop, 1 = proj_drop, 2 = MLP dropout of block `block`)."""
+    return (seed * 0x9E3779B9 + (3 * block + site + 1) * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, seed=0):
+    """Same stages as engine.forward, keeping what the backward needs in `sv`.  drop_p > 0 applies the three
+    nn.Dropout sites of every block (model.py:80-82,127,132,150) with stateless masks keyed by `seed`."""
+    sv = {"drop_p": float(drop_p), "seed": int(seed)}
     x = x.contiguous().float()
     B, _, H, W = x.shape
     sv["x"] = x
@@ -54,12 +61,14 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio):
         s = {"x_in": xw}
         s["y1"], s["mean1"], s["rstd1"] = ops.layernorm(xw, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], save_stats=True)
         s["qkv"] = ops.gemm_tokens(s["y1"], pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
-        s["att"] = ops.window_attn(s["qkv"], frags_t[i])
-        xm = s["x_mid"] = ops.gemm_tokens(s["att"], pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=xw)
+        s["att"] = ops.window_attn(s["qkv"], frags_t[i], drop_p, site_seed(seed, i, 0))
+        xm = s["x_mid"] = ops.gemm_tokens(s["att"], pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=xw,
+                                          drop_p=drop_p, drop_seed=site_seed(seed, i, 1))
         s["y2"], s["mean2"], s["rstd2"] = ops.layernorm(xm, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], save_stats=True)
         s["hpre"] = torch.empty((xm.shape[0], 768), dtype=BF16, device=x.device)
         s["hid"] = ops.gemm_tokens(s["y2"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"], "gelu", aux=s["hpre"])
-        xw = ops.gemm_tokens(s["hid"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"], "res", res=xm)
+        xw = ops.gemm_tokens(s["hid"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"], "res", res=xm,
+                             drop_p=drop_p, drop_seed=site_seed(seed, i, 2))
         blocks.append(s)
     sv["blocks"] = blocks
     sv["xw_out"] = xw
@@ -130,21 +139,28 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None) -> Dict[
     g_x = ops.patch_unembed_bwd(g_comb, pk["pu.wd"])
     ready("patch_unembed.weight", "patch_unembed.bias")
     # ---- transformer blocks (reverse) ----
+    drop_p, seed = sv["drop_p"], sv["seed"]
     for i in reversed(range(BLOCKS)):
         s, p = sv["blocks"][i], f"window_blocks.{i}"
-        g[p + ".mlp.2.bias"] = ops.colsum(g_x)
-        g[p + ".mlp.2.weight"] = ops.gemm_wgrad(g_x, s["hid"])
-        g_h = ops.gemm_tokens(g_x, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
+        # gradient entering mlp.2's output: through the MLP dropout mask (the residual path keeps g_x itself)
+        g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
+        g[p + ".mlp.2.bias"] = ops.colsum(g_o)
+        g[p + ".mlp.2.weight"] = ops.gemm_wgrad(g_o, s["hid"])
+        g_h = ops.gemm_tokens(g_o, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
+        del g_o
         g[p + ".mlp.0.bias"] = ops.colsum(g_h)
         g[p + ".mlp.0.weight"] = ops.gemm_wgrad(g_h, s["y2"])
         g_y2 = ops.gemm_tokens(g_h, pk[f"b{i}.fc1.wd"], None, "bf16")
         del g_h
         g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"] = ops.layernorm_bwd(
             g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
-        g[p + ".attn.proj.bias"] = ops.colsum(g_xm)
-        g[p + ".attn.proj.weight"] = ops.gemm_wgrad(g_xm, s["att"])
-        g_att = ops.gemm_tokens(g_xm, pk[f"b{i}.proj.wd"], None, "bf16")
-        g_qkv, g[p + ".attn.relative_position_bias_table"] = ops.window_attn_bwd(s["qkv"], g_att, frags_t[i], frags_n[i])
+        g_o = ops.dropout_bwd(g_xm, drop_p, site_seed(seed, i, 1)) if drop_p > 0 else g_xm      # proj_drop
+        g[p + ".attn.proj.bias"] = ops.colsum(g_o)
+        g[p + ".attn.proj.weight"] = ops.gemm_wgrad(g_o, s["att"])
+        g_att = ops.gemm_tokens(g_o, pk[f"b{i}.proj.wd"], None, "bf16")
+        del g_o
+        g_qkv, g[p + ".attn.relative_position_bias_table"] = ops.window_attn_bwd(
+            s["qkv"], g_att, frags_t[i], frags_n[i], drop_p, site_seed(seed, i, 0))
         g[p + ".attn.qkv.bias"] = ops.colsum(g_qkv)
         g[p + ".attn.qkv.weight"] = ops.gemm_wgrad(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.qkv.wd"], None, "bf16")
@@ -190,7 +206,8 @@ class _FastTransformerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, scale, res_out, require_ratio, names, *params):
         pk, frags_t, frags_n = module.packed(scale, backward=True)
-        out, sv = forward_train(pk, frags_t, x, scale, res_out, require_ratio)
+        drop_p, seed = module._next_dropout()
+        out, sv = forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p, seed)
         ctx.module, ctx.scale, ctx.names, ctx.sv = module, scale, names, sv
         ctx.pk, ctx.frags = pk, (frags_t, frags_n)
         return out

@@ -69,7 +69,8 @@ __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __r
 }
 
 __global__ __launch_bounds__(256) void window_attn_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ bias_frag, bf16_t* __restrict__ out, int npairs)
+    const bf16_t* __restrict__ qkv, const float* __restrict__ bias_frag, bf16_t* __restrict__ out, int npairs,
+    uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[4][NTOK * HD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,9 +149,16 @@ __global__ __launch_bounds__(256) void window_attn_kernel(
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            // normalise before the bf16 rounding of P (softmax output is what the reference multiplies by v)
-            const u32x2 pp = {pack_bf16x2(st[kt][qt][0] * inv[qt], st[kt][qt][1] * inv[qt]),
-                              pack_bf16x2(st[kt][qt][2] * inv[qt], st[kt][qt][3] * inv[qt])};
+            // normalise before the bf16 rounding of P (softmax output is what the reference multiplies by v);
+            // attn_drop (model.py:127): element index = (pair*64 + query)*64 + key
+            float pv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pv[e] = st[kt][qt][e] * inv[qt];
+                if (drop_thresh)
+                    pv[e] *= drop_scale(drop_seed, ((uint32_t)pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g + e, drop_thresh, drop_inv_keep);
+            }
+            const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
             o = mfma16x16x16(vf[kt], __builtin_bit_cast(s16x4, pp), o);
         }
         // O^T tile: rows = hd 4g+e, col = query p  ->  out[win][16qt+p][h*16 + 4g .. +3]
@@ -183,12 +191,16 @@ extern "C" int tup_relpos_bias_expand(const float* table, float* frag, void* str
 }
 
 // qkv: bf16 [nwin][64][576] (q | k | v, each head-major 12 x 16); out: bf16 [nwin][64][192].
-extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, void* stream)
+// drop_p > 0 applies attn_drop (model.py:80,127) with the stateless mask of common.h keyed by drop_seed.
+extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, float drop_p,
+                                   unsigned int drop_seed, void* stream)
 {
     if (nwin <= 0) return 0;
+    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
     const int npairs = nwin * HEADS;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     window_attn_kernel<<<dim3((npairs + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs);
+        (const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
     TUP_CHECK_LAUNCH();
     return 0;
 }

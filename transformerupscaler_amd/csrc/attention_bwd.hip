@@ -138,7 +138,8 @@ TUP_DEVICE s16x4 to_bf16x4(const f32x4 v) {
 
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ gout, const float* __restrict__ bias_t,
-    const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_t, int nwin, int nslots)
+    const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_t, int nwin, int nslots,
+    uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4][3][NTOK * HD];     // per wave: K, Q, dO as [tok][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
     for (int win = slot; win < nwin; win += nslots) {
         const bf16_t* base = qkv + (size_t)win * NTOK * (3 * DIM) + h * HD;
         const bf16_t* gbase = gout + (size_t)win * NTOK * DIM + h * HD;
+        const uint32_t pair = (uint32_t)win * HEADS + h;        // dropout element index = (pair*64 + query)*64 + key
         // stage K, Q, dO rows (lane = token) for the transposed (gather) fragments
         {
             const bf16_t* r = base + (size_t)lane * (3 * DIM);
@@ -221,7 +223,12 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { st[kt][e] *= inv; dsum += st[kt][e] * dpt[kt][e]; }
+                for (int e = 0; e < 4; ++e) {
+                    st[kt][e] *= inv;
+                    if (drop_thresh)     // O = D(P) V with D = mask/keep: dP = mask/keep * (dO V^T)
+                        dpt[kt][e] *= drop_scale(drop_seed, (pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g + e, drop_thresh, drop_inv_keep);
+                    dsum += st[kt][e] * dpt[kt][e];
+                }
             dsum += __shfl_xor(dsum, 16);
             dsum += __shfl_xor(dsum, 32);
             mrow[qt] = mx; irow[qt] = inv; drow[qt] = dsum;
@@ -259,7 +266,15 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     pr[e] = __expf(s[e] * 0.25f + bf[e] - mr[e]) * ir[e];
-                    ds[e] = pr[e] * (dp[e] - dr[e]);
+                    float dpe = dp[e];
+                    if (drop_thresh) {
+                        const float m = drop_scale(drop_seed, (pair * 64u + 16u * qt + 4u * g + e) * 64u + 16u * kt + p, drop_thresh, drop_inv_keep);
+                        dpe *= m;
+                        ds[e] = pr[e] * (dpe - dr[e]);
+                        pr[e] *= m;                    // dV uses the dropped probabilities
+                    } else {
+                        ds[e] = pr[e] * (dpe - dr[e]);
+                    }
                 }
                 dvT[kt] = mfma16x16x16(doT[qt], to_bf16x4(pr), dvT[kt]);   // dV^T[d][key] += dO^T[d][query] P[query][key]
                 dkT[kt] = mfma16x16x16(qT[qt], to_bf16x4(ds), dkT[kt]);    // dK^T[d][key] += Q^T[d][query] dS[query][key]
@@ -284,7 +299,34 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
                 atomicAdd(dbias_t + ((((size_t)h * 4 + kt) * 4 + qt) * 64 + lane) * 4 + e, dbacc[kt][qt][e]);
 }
 
+// gd = g * mask/keep (element index m*192 + n): gradient through proj_drop / the MLP's Dropout
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ gin, bf16_t* __restrict__ gout, size_t n4,
+                                                          uint32_t thresh, float inv_keep, uint32_t seed)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gin + 4 * i);
+        const uint32_t e0 = (uint32_t)(4 * i);
+        *reinterpret_cast<u32x2*>(gout + 4 * i) = u32x2{
+            pack_bf16x2(v[0] * drop_scale(seed, e0, thresh, inv_keep), v[1] * drop_scale(seed, e0 + 1, thresh, inv_keep)),
+            pack_bf16x2(v[2] * drop_scale(seed, e0 + 2, thresh, inv_keep), v[3] * drop_scale(seed, e0 + 3, thresh, inv_keep))};
+    }
+}
+
 }  // namespace
+
+// gout bf16 [M][192] = gin fp32 [M][192] * dropout mask / (1 - p): backward of nn.Dropout after proj / mlp.2
+// (model.py:82,132,150) with the mask the forward epilogue used (same seed).
+extern "C" int tup_dropout_bwd(const float* gin, void* gout, long long n, float drop_p, unsigned int drop_seed, void* stream)
+{
+    if (n <= 0) return 0;
+    if (n % 4 != 0 || drop_p <= 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dropout_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        gin, (bf16_t*)gout, (size_t)(n / 4), (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p), drop_seed);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
 
 // dx = LN'(gy) [+ gres]; dgamma/dbeta (fp32 [192]) are accumulated (caller zeroes them).
 extern "C" int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
@@ -311,13 +353,17 @@ extern "C" int tup_relpos_bias_expand_n(const float* table, float* frag, void* s
 // qkv bf16 [nwin][64][576], gout bf16 [nwin][64][192] (grad of the attention output before proj) ->
 // gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] accumulated (caller zeroes).
 extern "C" int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                                   void* gqkv, float* dbias_t, int nwin, void* stream)
+                                   void* gqkv, float* dbias_t, int nwin, float drop_p, unsigned int drop_seed,
+                                   void* stream)
 {
     if (nwin <= 0) return 0;
+    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     int nslots = nwin < 128 ? nwin : 128;
     const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
     window_attn_bwd_kernel<<<dim3(nwaves / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, dbias_t, nwin, nslots);
+        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, dbias_t, nwin, nslots,
+        thresh, 1.0f / (1.0f - drop_p), drop_seed);
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -44,4 +44,16 @@ TUP_DEVICE float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// Stateless dropout mask: keep(element) = hash(seed, element index) >= thresh, thresh = p * 2^32.
+// The same function is evaluated by the forward and the backward kernels (nothing is stored) and by the
+// CPU checker in tests (tests/test_hip_dropout.py), bit for bit.
+TUP_DEVICE uint32_t drop_hash(uint32_t seed, uint32_t idx) {
+    uint32_t h = idx * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+TUP_DEVICE float drop_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
+    return drop_hash(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+
 #define TUP_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -28,6 +28,7 @@ struct GemmParams {
     const float* res;            // E_RES_F32: [M][ldo] fp32
     const bf16_t* skip;          // E_UNEMBED: NHWC feat to add (or null); E_GELU_BWD: pre-activation [M][ldo]
     int reflect;                 // A_PATCH: 1 = reflect-pad beyond the map, 0 = zeros
+    uint32_t drop_thresh, drop_seed; float drop_inv_keep;      // E_RES_F32: dropout on (acc + bias) before "+ res"
     int M, N, K;
     int H, W, Ht, Wt_, nWx, nWy; // geometry for the patch modes (token rows are in window layout)
 };
@@ -224,7 +225,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
                 const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + 4 * q);
                 f32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = v[4 * q + e] + bvec[4 * q + e] + rv[e];
+                for (int e = 0; e < 4; ++e) {
+                    float t = v[4 * q + e] + bvec[4 * q + e];
+                    if (p.drop_thresh)      // proj_drop / mlp Dropout (model.py:132,150): element index m*ldo + n
+                        t *= drop_scale(p.drop_seed, (uint32_t)m * (uint32_t)p.ldo + nb + 4 * q + e, p.drop_thresh, p.drop_inv_keep);
+                    ov[e] = t + rv[e];
+                }
                 *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
             }
         } else if constexpr (EPI == E_PATCH_EMBED) {
@@ -296,11 +302,18 @@ int launch(const GemmParams& p, hipStream_t s)
 //           3 = * gelu'(aux) -> bf16 (aux = bf16 [M][ldo] pre-activation; backward of model.py:148).
 //           With epilogue 1 a non-NULL aux is an OUTPUT: the bf16 pre-activation is saved there.
 // a_dtype: 0 = bf16 A, 1 = fp32 A (converted to bf16 on the way into LDS).  bias may be NULL for 0 and 3.
+// drop_p > 0 (epilogue 2 only): out = dropout(acc + bias) + res with the stateless mask of common.h.
 extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, const float* bias,
                                    const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
-                                   int epilogue, void* stream)
+                                   int epilogue, float drop_p, unsigned int drop_seed, void* stream)
 {
     GemmParams p{};
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && epilogue != 2)) return (int)hipErrorInvalidValue;
+    if (drop_p > 0.f) {
+        p.drop_thresh = (uint32_t)((double)drop_p * 4294967296.0);
+        p.drop_inv_keep = 1.0f / (1.0f - drop_p);
+        p.drop_seed = drop_seed;
+    }
     p.A = A; p.lda = lda; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.ldo = ldo; p.res = res;
     p.skip = (const bf16_t*)aux;
     p.M = M; p.N = N; p.K = K;

@@ -132,6 +132,17 @@ class TransformerModel(nn.Module):
         self.decoder_conv1 = _ConvParams(base_channels, base_channels, 3)
         self.decoder_conv2 = _ConvParams(base_channels, in_channels, 3)
         self._pack_cache: Dict[int, tuple] = {}
+        self._dropout_calls = 0
+
+    def _next_dropout(self):
+        """(p, seed) for the next training forward: p = 0 in eval mode; the seed advances every call and is
+        offset by torch's seed and the data-parallel rank so replicas draw different masks."""
+        if not self.training or self.dropout_p <= 0.0:
+            return 0.0, 0
+        import os
+        self._dropout_calls += 1
+        base = (torch.initial_seed() + 7919 * int(os.environ.get("RANK", "0"))) & 0x7FFFFFFF
+        return self.dropout_p, (base * 2654435761 + self._dropout_calls) & 0xFFFFFFFF
 
     # ---- packed-weight cache, invalidated by in-place parameter updates (optimizer steps) ----
     def _versions(self):

@@ -142,16 +142,16 @@ def relpos_bias_expand(table):
     return frag
 
 
-def window_attn(qkv, bias_frag):
+def window_attn(qkv, bias_frag, drop_p=0.0, drop_seed=0):
     M, D = qkv.shape
     assert D == 576 and M % 64 == 0
     out = torch.empty((M, 192), dtype=BF16, device=qkv.device)
     _lib.call("tup_window_attn_fwd", _chk(qkv, BF16, None, "qkv"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
-              out.data_ptr(), M // 64, _stream())
+              out.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     return out
 
 
-def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None):
+def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None, drop_p=0.0, drop_seed=0):
     """epilogue 'bf16' | 'gelu' (aux, if given, receives the bf16 pre-activation) | 'res' (fp32 out = a@wt^T + bias
     + res) | 'gelu_bwd' (bf16 out = (a@wt^T) * gelu'(aux))."""
     M, K = a.shape
@@ -170,7 +170,8 @@ def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None):
         if epi == 3 or (epi == 1 and aux is not None):
             auxp = _chk(aux, BF16, (M, N), "aux")
     _lib.call("tup_gemm_tokens_fwd", _chk(a, a.dtype, None, "a"), a_dtype, K, _chk(wt, BF16, None, "wt"),
-              _opt(bias, F32, (N,), "bias"), resp, auxp, out.data_ptr(), N, M, N, K, epi, _stream())
+              _opt(bias, F32, (N,), "bias"), resp, auxp, out.data_ptr(), N, M, N, K, epi, float(drop_p),
+              int(drop_seed) & 0xFFFFFFFF, _stream())
     return out
 
 
@@ -252,7 +253,14 @@ def relpos_bias_expand_n(table):
     return frag
 
 
-def window_attn_bwd(qkv, gout, bias_t, bias_n):
+def dropout_bwd(g, drop_p, drop_seed):
+    """bf16 [M][192] = fp32 g * mask / (1 - p) for the site keyed by drop_seed."""
+    out = torch.empty(g.shape, dtype=BF16, device=g.device)
+    _lib.call("tup_dropout_bwd", _chk(g, F32, None, "g"), out.data_ptr(), g.numel(), float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+    return out
+
+
+def window_attn_bwd(qkv, gout, bias_t, bias_n, drop_p=0.0, drop_seed=0):
     """returns (gqkv bf16 [M][576], dtable fp32 [225][12])."""
     M = qkv.shape[0]
     assert M % 64 == 0
@@ -260,7 +268,7 @@ def window_attn_bwd(qkv, gout, bias_t, bias_n):
     dbias = torch.zeros((12, 4, 4, 64, 4), dtype=F32, device=qkv.device)
     _lib.call("tup_window_attn_bwd", _chk(qkv, BF16, (M, 576), "qkv"), _chk(gout, BF16, (M, 192), "gout"),
               _chk(bias_t, F32, (12, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (12, 4, 4, 64, 4), "bias_n"),
-              gqkv.data_ptr(), dbias.data_ptr(), M // 64, _stream())
+              gqkv.data_ptr(), dbias.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     dtable = torch.empty((225, 12), dtype=F32, device=qkv.device)
     _lib.call("tup_relpos_bias_reduce", dbias.data_ptr(), dtable.data_ptr(), _stream())
     return gqkv, dtable

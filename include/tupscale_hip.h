@@ -100,6 +100,12 @@ int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, con
                         const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
                         int epilogue, float drop_p, unsigned int drop_seed, void* stream);
 
+/* Inference fusion of the MLP half of a block: x += mlp.2(GELU(mlp.0(norm2(x)))) (model.py:144-151,168-171);
+ * the [M][768] hidden tensor stays in LDS.  x fp32 [M][192] in place; w1 bf16 [768][192], w2 bf16 [192][768]
+ * (rows permuted per 64-group). */
+int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta, const void* w1, const float* b1,
+                      const void* w2, const float* b2, int M, void* stream);
+
 /* reflect pad + patch_embed Conv2d(64,192,k8,s8) + NHWC permute + zero token pad +
  * window_partition: model.py:256-261,268-285.  feat bf16 NHWC; Wt bf16 [192][4096],
  * k = (i*8+j)*64+c; x_out fp32 window layout. */

@@ -383,3 +383,23 @@ def test_feat_grad_combine(dev, hw):
     ref = (a + b + f.grad) * (feat > 0)
     got = ops.feat_grad_combine(nhwc(a).to(dev), nhwc(b).to(dev), nhwc(gpe).to(dev), nhwc(feat).to(dev))
     close(got, ref.permute(0, 2, 3, 1), 2e-2, 1e-2, "feat grad combine")
+
+
+@pytest.mark.parametrize("M", [128, 320, 64 * 7])
+def test_fused_mlp(dev, M):
+    """Inference fusion LN2 -> mlp.0 -> GELU -> mlp.2 -> +residual against torch and the unfused kernels."""
+    from transformerupscaler_amd import ops, packing
+    x = rnd((M, 192), 80, 2.0, 0.3)
+    gm, bt = rnd((192,), 81, 0.1, 1.0), rnd((192,), 82, 0.1)
+    w1, b1 = rnd((768, 192), 83, 0.08), rnd((768,), 84, 0.2)
+    w2, b2 = rnd((192, 768), 85, 0.05), rnd((192,), 86, 0.2)
+    y = bf(F.layer_norm(x, (192,), gm, bt, 1e-5))
+    ref = x + F.linear(bf(F.gelu(F.linear(y, bf(w1), b1))), bf(w2), b2)
+    w1p, w2p = packing.pack_linear(w1).to(dev), packing.pack_linear(w2).to(dev)
+    got = ops.fused_mlp(x.to(dev).clone(), gm.to(dev), bt.to(dev), w1p, b1.to(dev), w2p, b2.to(dev))
+    close(got, ref, 2e-2, 1e-2, "fused mlp vs torch")
+    xu = x.to(dev).clone()
+    yl = ops.layernorm(xu, gm.to(dev), bt.to(dev))
+    hid = ops.gemm_tokens(yl, w1p, b1.to(dev), "gelu")
+    ops.gemm_tokens(hid, w2p, b2.to(dev), "res", res=xu, out=xu)
+    close(got, xu, 2e-3, 1e-3, "fused mlp vs unfused kernels")

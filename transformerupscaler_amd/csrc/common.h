@@ -18,6 +18,22 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define TUP_DEVICE __device__ __forceinline__
 
+// ---- LDS reads the compiler does not track (hand-pipelined MFMA loops) ----
+// hipcc sinks every ds_read to just above its first use and waits lgkmcnt(0) there; at one or two waves per
+// SIMD that exposes the LDS latency in front of every few MFMAs.  These helpers issue ds_read_b128 from
+// inline asm (invisible to the waitcnt pass) so the caller can request the next K-step's fragments early and
+// wait with a hand-counted lgkmcnt(N); follow the wait with __builtin_amdgcn_sched_barrier(0) so the MFMAs
+// stay below it (guide 5.4 rule 18).  No compiler-visible LDS access may be in flight across such a section.
+TUP_DEVICE uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(p);
+}
+TUP_DEVICE bf16x8 lds_read_b128_asm(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N> TUP_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
 TUP_DEVICE float bf16_to_f32(bf16_t v) { return static_cast<float>(v); }
 TUP_DEVICE bf16_t f32_to_bf16(float v) { return static_cast<bf16_t>(v); }   // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
 
@@ -38,10 +54,39 @@ TUP_DEVICE f32x4 mfma16x16x16(s16x4 a, s16x4 b, f32x4 c) {
 // lane group touches land on 16 distinct 16-byte slots of the 256-byte bank row.
 TUP_DEVICE int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-TUP_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(z) ~= zc * Q(zc^2), zc = clamp(z, +-2.9), Q = degree-9 Chebyshev fit of erf(z)/z on [0, 2.9^2]:
+// |error| <= 4.2e-5 in erf (8.5e-5 in GELU, below the bf16 rounding of every consumer), pure FMA chain --
+// no v_exp / v_rcp (libm erff is ~40 instructions; the GELU epilogue of mlp.0 evaluates 94 M of these per
+// 8-image forward and was VALU-bound on it).  The f32x2 form lets hipcc emit v_pk_fma_f32 (2 values / issue).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+TUP_DEVICE f32x2 fast_erf2(f32x2 z) {
+    f32x2 zc;
+    zc[0] = fminf(fmaxf(z[0], -2.9f), 2.9f);
+    zc[1] = fminf(fmaxf(z[1], -2.9f), 2.9f);
+    const f32x2 w = zc * zc;
+    f32x2 q = w * -5.423542948079785e-09f + 2.6428506316733547e-07f;
+    q = q * w + -5.823991614306578e-06f;
+    q = q * w + 7.786024070810527e-05f;
+    q = q * w + -0.000718351046089083f;
+    q = q * w + 0.004940473474562168f;
+    q = q * w + -0.026508823037147522f;
+    q = q * w + 0.11259414255619049f;
+    q = q * w + -0.37605419754981995f;
+    q = q * w + 1.1283738613128662f;
+    return zc * q;
+}
+TUP_DEVICE float fast_erf(float z) { return fast_erf2(f32x2{z, z})[0]; }
+
+// nn.GELU() default = exact erf form (reference model.py:148)
+TUP_DEVICE f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 hx = x * 0.5f;
+    return hx * fast_erf2(x * 0.70710678118654752440f) + hx;
+}
+TUP_DEVICE float gelu_erf(float x) { return gelu_erf2(f32x2{x, x})[0]; }
 
 TUP_DEVICE float gelu_erf_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
 // Stateless dropout mask: keep(element) = hash(seed, element index) >= thresh, thresh = p * 2^32.

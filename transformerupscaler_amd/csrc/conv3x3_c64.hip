@@ -230,17 +230,6 @@ __global__ __launch_bounds__(256, (CT <= 4 && KS == 3) ? 2 : 1) void conv3x3_c64
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned int tup_zero_line[4] = {0u, 0u, 0u, 0u};
 
-TUP_DEVICE uint32_t lds_addr(const void* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(p);
-}
-// ds_read the compiler does not track: the caller owns the wait (lds_wait) before the first use.
-TUP_DEVICE bf16x8 lds_read_b128_asm(uint32_t addr) {
-    bf16x8 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-template <int N> TUP_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-
 template <int CT, int OUT_MODE, int KS>
 __global__ __launch_bounds__(256, 1) void conv_c64_persistent_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,

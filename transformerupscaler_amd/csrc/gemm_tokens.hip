@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
                 float a = v[2 * q] + bvec[2 * q], b = v[2 * q + 1] + bvec[2 * q + 1];
                 if constexpr (EPI == E_GELU_BF16) {
                     ppre[q] = pack_bf16x2(a, b);      // pre-activation, saved (bf16) by the training path
-                    a = gelu_erf(a);
-                    b = gelu_erf(b);
+                    const f32x2 gv = gelu_erf2(f32x2{a, b});
+                    a = gv[0];
+                    b = gv[1];
                 }
                 pk[q] = pack_bf16x2(a, b);
             }

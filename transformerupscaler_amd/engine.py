@@ -42,6 +42,9 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
     return (int(res_out[0]), int(res_out[1])), int(upscale_factor)
 
 
+fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
+
+
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     for i in range(BLOCKS):
@@ -49,9 +52,13 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
         qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
         att = ops.window_attn(qkv, bias_frags[i])
         ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=x, out=x)
-        y = ops.layernorm(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"])
-        hid = ops.gemm_tokens(y, pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"], "gelu")
-        ops.gemm_tokens(hid, pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"], "res", res=x, out=x)
+        if fuse_blocks:
+            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"],
+                          pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
+        else:
+            y = ops.layernorm(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"])
+            hid = ops.gemm_tokens(y, pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"], "gelu")
+            ops.gemm_tokens(hid, pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"], "res", res=x, out=x)
         if capture is not None:
             capture[f"block{i}"] = x.clone()
             capture[f"block{i}_qkv"] = qkv

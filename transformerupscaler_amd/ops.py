@@ -175,6 +175,15 @@ def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None, drop_p=0.0,
     return out
 
 
+def fused_mlp(x, gamma, beta, w1, b1, w2, b2):
+    """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip)."""
+    M = x.shape[0]
+    _lib.call("tup_fused_mlp_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma, F32, (192,), "gamma"), _chk(beta, F32, (192,), "beta"),
+              _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, BF16, (192, 768), "w2"),
+              _chk(b2, F32, (192,), "b2"), M, _stream())
+    return x
+
+
 def window_geometry(H, W):
     ht, wt = (H + 7) // 8, (W + 7) // 8
     nwy, nwx = (ht + 7) // 8, (wt + 7) // 8

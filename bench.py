@@ -112,7 +112,7 @@ def main():
         from transformerupscaler_amd.dp import DataParallel
         tm = importlib.import_module("models.FastTransformer.model").TransformerModel()
         tm.load_state_dict(deterministic_state_dict(0), strict=False)
-        tm = tm.to(dev).eval()      # dropout is not applied on the HIP training path yet (eval graph with grads)
+        tm = tm.to(dev).train()     # dropout p=0.1 active (model.py:80-82,127,132,150), as in train.py:109
         dp = DataParallel(tm, scale=2) if world > 1 else None
         opt = harness.make_optimizer(tm, 1e-4)
         gt = torch.Generator().manual_seed(4321 + rank)
@@ -136,7 +136,7 @@ def main():
         del dp
         return {"metric": "images/sec, FastTransformer 2x 720p->1080p training step", "value": world * args.train_batch * args.steps / dtt,
                 "unit": "images/sec", "ms_per_step": dtt / args.steps * 1e3, "images_per_gpu_per_step": args.train_batch,
-                "global_batch": world * args.train_batch, "loss": float(loss.item()), "dropout": "off (eval graph)",
+                "global_batch": world * args.train_batch, "loss": float(loss.item()), "dropout": "p=0.1 (train mode, stateless hash masks)",
                 "parallelism": f"dp{world}" + (" RCCL all-reduce of 17.9 MB fp32 grads in ~6 MB buckets, overlapped with backward" if world > 1 else ""),
                 "optimizer": "Adam lr 1e-4 (torch.optim)", "loss_fn": "L1 vs synthetic HR after antialiased resize 1440x2560 -> 1080x1920"}
 
@@ -173,6 +173,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    traffic = None       # HBM bytes per launch of the dominant kernel from a committed PMC run (profiles/), not measured live
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv64.json")) as f:
+            pm = json.load(f)
+        if args.batch == 8:
+            traffic = pm["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
     achieved = CONV64_FLOP_PER_IMAGE * args.batch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
 
@@ -189,9 +197,11 @@ def main():
                                    f"batch {args.batch} per GPU (BASELINE.json configs[1])",
                        "images_per_gpu_per_step": args.batch, "parallelism": f"replicas x{world}",
                        "weights": "deterministic synthetic (transformerupscaler_amd.weights, seed 0)"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_c64_kernel<4,0,3> (conv2 64->64 3x3 implicit GEMM; same kernel as decoder_conv1)",
+            "roofline": {"bound": "mfma", "kernel": "conv_c64_persistent_kernel<4,0,3> (conv2 64->64 3x3 implicit GEMM; same kernel as decoder_conv1)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic_conv64.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                         "algorithmic_bytes": 2 * args.batch * LR_H * LR_W * 64 * 2,
                          "ms_per_launch": kern_ms, "launches_timed": len(events)},
         }
         if train_result is not None:

@@ -100,6 +100,10 @@ int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const void* Wt, con
                         const float* res, const void* aux, void* out, int ldo, int M, int N, int K,
                         int epilogue, float drop_p, unsigned int drop_seed, void* stream);
 
+/* norm1 fused into attn.qkv (model.py:163 + :115): out bf16 [M][N] = LayerNorm(x) Wt^T + bias; x fp32 [M][192]. */
+int tup_ln_gemm_fwd(const float* x, const float* gamma, const float* beta, const void* Wt,
+                    const float* bias, void* out, int M, int N, void* stream);
+
 /* Inference fusion of the MLP half of a block: x += mlp.2(GELU(mlp.0(norm2(x)))) (model.py:144-151,168-171);
  * the [M][768] hidden tensor stays in LDS.  x fp32 [M][192] in place; w1 bf16 [768][192], w2 bf16 [192][768]
  * (rows permuted per 64-group). */

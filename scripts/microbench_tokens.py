@@ -31,3 +31,10 @@ def unfused_attn():
 print("unfused_attn %.1f us" % timeit(unfused_attn))
 if hasattr(ops, "fused_attn"):
     print("fused_attn  %.1f us" % timeit(lambda: ops.fused_attn(x, gm, bt, wq, bq, frag, wp, bp)))
+print("ln+qkv panel %.1f us" % timeit(lambda: ops.ln_gemm(x, gm, bt, wq, bq)))
+y_ = ops.layernorm(x, gm, bt)
+print("qkv gemm    %.1f us" % timeit(lambda: ops.gemm_tokens(y_, wq, bq, "bf16")))
+a_ = ops.window_attn(ops.gemm_tokens(y_, wq, bq, "bf16"), frag)
+print("attn core   %.1f us" % timeit(lambda: ops.window_attn(ops.gemm_tokens(y_, wq, bq, "bf16"), frag)))
+print("proj+res    %.1f us" % timeit(lambda: ops.gemm_tokens(a_, wp, bp, "res", res=x, out=x)))
+print("fc1 gelu    %.1f us" % timeit(lambda: ops.gemm_tokens(y_, w1, b1, "gelu")))

@@ -403,3 +403,14 @@ def test_fused_mlp(dev, M):
     hid = ops.gemm_tokens(yl, w1p, b1.to(dev), "gelu")
     ops.gemm_tokens(hid, w2p, b2.to(dev), "res", res=xu, out=xu)
     close(got, xu, 2e-3, 1e-3, "fused mlp vs unfused kernels")
+
+
+def test_ln_gemm_fused(dev):
+    from transformerupscaler_amd import ops, packing
+    M, N = 448, 576
+    x = rnd((M, 192), 90, 2.0, 0.3)
+    gm, bt = rnd((192,), 91, 0.1, 1.0), rnd((192,), 92, 0.1)
+    w, b = rnd((N, 192), 93, 0.08), rnd((N,), 94, 0.2)
+    ref = F.linear(bf(F.layer_norm(x, (192,), gm, bt, 1e-5)), bf(w), b)
+    got = ops.ln_gemm(x.to(dev), gm.to(dev), bt.to(dev), packing.pack_linear(w).to(dev), b.to(dev))
+    close(got, ref, 2e-2, 1e-2, "LN + GEMM panel kernel")

@@ -31,6 +31,7 @@ SIGNATURES = {
     "tup_relpos_bias_expand": [P, P, P],
     "tup_window_attn_fwd": [P, P, P, I, F, U, P],
     "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, P, I, I, I, I, I, F, U, P],
+    "tup_ln_gemm_fwd": [P, P, P, P, P, P, I, I, P],
     "tup_fused_mlp_fwd": [P, P, P, P, P, P, P, I, P],
     "tup_patch_embed_fwd": [P, P, P, P, I, I, I, P],
     "tup_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],

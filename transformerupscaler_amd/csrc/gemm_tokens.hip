@@ -14,10 +14,11 @@
 // Weight rows are pre-permuted on the host inside every 64-row group (row ct*16+4g+e holds
 // feature g*16+ct*4+e) to make that true.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-enum { A_BF16 = 0, A_F32 = 1, A_PATCH = 2 };
+enum { A_BF16 = 0, A_F32 = 1, A_PATCH = 2, A_LN = 3 };
 enum { E_BF16 = 0, E_GELU_BF16 = 1, E_RES_F32 = 2, E_PATCH_EMBED = 3, E_UNEMBED = 4, E_GELU_BWD = 5 };
 
 struct GemmParams {
@@ -29,6 +30,7 @@ struct GemmParams {
     const bf16_t* skip;          // E_UNEMBED: NHWC feat to add (or null); E_GELU_BWD: pre-activation [M][ldo]
     int reflect;                 // A_PATCH: 1 = reflect-pad beyond the map, 0 = zeros
     uint32_t drop_thresh, drop_seed; float drop_inv_keep;      // E_RES_F32: dropout on (acc + bias) before "+ res"
+    const float* ln_gamma; const float* ln_beta;               // panel kernel, A_LN: LayerNorm fused into the A load
     int M, N, K;
     int H, W, Ht, Wt_, nWx, nWy; // geometry for the patch modes (token rows are in window layout)
 };
@@ -49,6 +51,113 @@ TUP_DEVICE TokPos token_of_row(int m, const GemmParams& p) {
     t.tx = wx * 8 + (tok & 7);
     t.valid = (t.ty < p.Ht) && (t.tx < p.Wt_);
     return t;
+}
+
+// Epilogue of one token row: the lane holds v[16] = features n0 + g*16 .. +15 of row m (accumulators), bvec = the
+// matching bias values.  Shared by the K-streaming kernel and the A-resident panel kernel.
+template <int EPI>
+TUP_DEVICE void gemm_store_row(const GemmParams& p, int m, int n0, int g, const float (&v)[16], const float (&bvec)[16])
+{
+    const int nb = n0 + g * 16;
+    if constexpr (EPI == E_BF16 || EPI == E_GELU_BF16) {
+        uint32_t pk[8], ppre[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float a = v[2 * q] + bvec[2 * q], b = v[2 * q + 1] + bvec[2 * q + 1];
+            if constexpr (EPI == E_GELU_BF16) {
+                ppre[q] = pack_bf16x2(a, b);      // pre-activation, saved (bf16) by the training path
+                const f32x2 gv = gelu_erf2(f32x2{a, b});
+                a = gv[0];
+                b = gv[1];
+            }
+            pk[q] = pack_bf16x2(a, b);
+        }
+        if constexpr (EPI == E_GELU_BF16) {
+            if (p.skip) {
+                bf16_t* po = const_cast<bf16_t*>(p.skip) + (size_t)m * p.ldo + nb;
+                *reinterpret_cast<u32x4*>(po) = u32x4{ppre[0], ppre[1], ppre[2], ppre[3]};
+                *reinterpret_cast<u32x4*>(po + 8) = u32x4{ppre[4], ppre[5], ppre[6], ppre[7]};
+            }
+        }
+        bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    } else if constexpr (EPI == E_RES_F32) {
+        float* o = (float*)p.out + (size_t)m * p.ldo + nb;
+        const float* rs = p.res + (size_t)m * p.ldo + nb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + 4 * q);
+            f32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[4 * q + e] + bvec[4 * q + e];
+                if (p.drop_thresh)      // proj_drop / mlp Dropout (model.py:132,150): element index m*ldo + n
+                    t *= drop_scale(p.drop_seed, (uint32_t)m * (uint32_t)p.ldo + nb + 4 * q + e, p.drop_thresh, p.drop_inv_keep);
+                ov[e] = t + rv[e];
+            }
+            *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
+        }
+    } else if constexpr (EPI == E_PATCH_EMBED) {
+        // zero-padded tokens are exact zeros (no bias): model.py:273-280
+        const TokPos t = token_of_row(m, p);
+        float* o = (float*)p.out + (size_t)m * p.ldo + nb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + bvec[4 * q + e] : 0.f;
+            *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
+        }
+    } else if constexpr (EPI == E_GELU_BWD) {
+        // out = acc * gelu'(pre), pre = saved fc1 output before the activation (model.py:148)
+        const bf16_t* pr = p.skip + (size_t)m * p.ldo + nb;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(pr), a1 = *reinterpret_cast<const u32x4*>(pr + 8);
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t sw = (q < 4) ? a0[q & 3] : a1[q & 3];
+            const float xa = __builtin_bit_cast(float, sw << 16), xb = __builtin_bit_cast(float, sw & 0xffff0000u);
+            pk[q] = pack_bf16x2(v[2 * q] * gelu_erf_grad(xa), v[2 * q + 1] * gelu_erf_grad(xb));
+        }
+        bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    } else {  // E_UNEMBED: n tile = patch pixel (i, j); features = base channel o
+        const TokPos t = token_of_row(m, p);
+        const int pix = n0 >> 6, i = pix >> 3, j = pix & 7;
+        const int py = t.ty * 8 + i, px = t.tx * 8 + j;
+        if (!t.valid || py >= p.H || px >= p.W) return;
+        const size_t off = (((size_t)t.b * p.H + py) * p.W + px) * 64 + g * 16;
+        u32x4 s0 = {0u, 0u, 0u, 0u}, s1 = {0u, 0u, 0u, 0u};
+        if (p.skip) {
+            s0 = *reinterpret_cast<const u32x4*>(p.skip + off);
+            s1 = *reinterpret_cast<const u32x4*>(p.skip + off + 8);
+        }
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t sw = (q < 4) ? s0[q & 3] : s1[q & 3];
+            const float sa = __builtin_bit_cast(float, sw << 16);
+            const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
+            pk[q] = pack_bf16x2(v[2 * q] + bvec[2 * q] + sa, v[2 * q + 1] + bvec[2 * q + 1] + sb);
+        }
+        bf16_t* o = (bf16_t*)p.out + off;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    }
+}
+
+TUP_DEVICE void gemm_load_bias(const GemmParams& p, int n0, int g, bool unembed, float (&bvec)[16])
+{
+    const int bb = unembed ? g * 16 : n0 + g * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) t = *reinterpret_cast<const f32x4*>(p.bias + bb + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bvec[4 * q + e] = t[e];
+    }
 }
 
 template <int AMODE, int EPI>
@@ -174,16 +283,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
 
     // ---- epilogue: lane holds features n0 + g*16 + ct*4 + e of token row m ----
     float bvec[16];
-    {
-        const int bb = (EPI == E_UNEMBED) ? g * 16 : n0 + g * 16;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) t = *reinterpret_cast<const f32x4*>(p.bias + bb + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bvec[4 * q + e] = t[e];
-        }
-    }
+    gemm_load_bias(p, n0, g, EPI == E_UNEMBED, bvec);
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
         const int m = m0 + 32 * wave + 16 * tg + pl;
@@ -193,96 +293,178 @@ __global__ __launch_bounds__(256, 2) void gemm_tokens_kernel(const GemmParams p)
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ct][e];
-        const int nb = n0 + g * 16;
+        gemm_store_row<EPI>(p, m, n0, g, v, bvec);
+    }
+}
 
-        if constexpr (EPI == E_BF16 || EPI == E_GELU_BF16) {
-            uint32_t pk[8], ppre[8];
+// ------------------------------------------------------------------------------------------------
+// A-resident "panel" kernel for K = 192 (every Linear that reads the 192-wide token stream, and
+// patch_unembed): the [128][192] token tile is loaded ONCE per workgroup -- optionally through a fused
+// LayerNorm (A_LN) -- and stays in LDS while the workgroup walks all N/64 weight tiles, each streamed
+// global -> registers -> LDS one tile ahead.  The K-streaming kernel above pays a global-load round trip
+// per 16 MFMAs at K = 192 (3 iterations per output tile) and was latency-bound; here it is paid once
+// per 128 rows.  LDS: 48 KB (A) + 24 KB (W) -> two workgroups per CU.  Fragment reads are hand-pipelined.
+// ------------------------------------------------------------------------------------------------
+constexpr int PK = 192, PBM = 128;
+constexpr int PA_BYTES = 3 * PBM * 128, PW_BYTES = 3 * 64 * 128;
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* a_lds = smem;
+    char* w_lds = smem + PA_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    const int m0 = blockIdx.x * PBM;
+    const int ntiles = p.N / 64;
+
+    u32x4 wreg[6];
+    auto load_w = [&](int nt) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float a = v[2 * q] + bvec[2 * q], b = v[2 * q + 1] + bvec[2 * q + 1];
-                if constexpr (EPI == E_GELU_BF16) {
-                    ppre[q] = pack_bf16x2(a, b);      // pre-activation, saved (bf16) by the training path
-                    const f32x2 gv = gelu_erf2(f32x2{a, b});
-                    a = gv[0];
-                    b = gv[1];
-                }
-                pk[q] = pack_bf16x2(a, b);
-            }
-            if constexpr (EPI == E_GELU_BF16) {
-                if (p.skip) {
-                    bf16_t* po = const_cast<bf16_t*>(p.skip) + (size_t)m * p.ldo + nb;
-                    *reinterpret_cast<u32x4*>(po) = u32x4{ppre[0], ppre[1], ppre[2], ppre[3]};
-                    *reinterpret_cast<u32x4*>(po + 8) = u32x4{ppre[4], ppre[5], ppre[6], ppre[7]};
-                }
-            }
-            bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
-            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-        } else if constexpr (EPI == E_RES_F32) {
-            float* o = (float*)p.out + (size_t)m * p.ldo + nb;
-            const float* rs = p.res + (size_t)m * p.ldo + nb;
+        for (int u = 0; u < 6; ++u) {
+            const int idx = tid + u * 256;                  // 1536 chunks: row = idx / 24, c = idx % 24
+            const int row = idx / 24, c = idx - row * 24;
+            wreg[u] = *reinterpret_cast<const u32x4*>(p.Wt + (size_t)(nt * 64 + row) * PK + c * 8);
+        }
+    };
+    auto store_w = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + 4 * q);
-                f32x4 ov;
+        for (int u = 0; u < 6; ++u) {
+            const int idx = tid + u * 256;
+            const int row = idx / 24, c = idx - row * 24;
+            *reinterpret_cast<u32x4*>(w_lds + (c >> 3) * (64 * 128) + swz128(row, c & 7)) = wreg[u];
+        }
+    };
+    load_w(0);
+
+    // ---- A tile prologue ----
+    if constexpr (AMODE == A_LN) {
+        const int sub = tid & 15;
+        f32x4 gm[3], bt[3];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = v[4 * q + e] + bvec[4 * q + e];
-                    if (p.drop_thresh)      // proj_drop / mlp Dropout (model.py:132,150): element index m*ldo + n
-                        t *= drop_scale(p.drop_seed, (uint32_t)m * (uint32_t)p.ldo + nb + 4 * q + e, p.drop_thresh, p.drop_inv_keep);
-                    ov[e] = t + rv[e];
-                }
-                *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
-            }
-        } else if constexpr (EPI == E_PATCH_EMBED) {
-            // zero-padded tokens are exact zeros (no bias): model.py:273-280
-            const TokPos t = token_of_row(m, p);
-            float* o = (float*)p.out + (size_t)m * p.ldo + nb;
+        for (int q = 0; q < 3; ++q) {
+            gm[q] = *reinterpret_cast<const f32x4*>(p.ln_gamma + q * 64 + sub * 4);
+            bt[q] = *reinterpret_cast<const f32x4*>(p.ln_beta + q * 64 + sub * 4);
+        }
+#pragma unroll 2
+        for (int pass = 0; pass < PBM / 16; ++pass) {
+            const int r = pass * 16 + (tid >> 4);
+            const int m = min(m0 + r, p.M - 1);
+            f32x4 v[3];
+            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 ov;
+            for (int q = 0; q < 3; ++q) {
+                v[q] = *reinterpret_cast<const f32x4*>((const float*)p.A + (size_t)m * p.lda + q * 64 + sub * 4);
+                sum += v[q][0] + v[q][1] + v[q][2] + v[q][3];
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + bvec[4 * q + e] : 0.f;
-                *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
-            }
-        } else if constexpr (EPI == E_GELU_BWD) {
-            // out = acc * gelu'(pre), pre = saved fc1 output before the activation (model.py:148)
-            const bf16_t* pr = p.skip + (size_t)m * p.ldo + nb;
-            const u32x4 a0 = *reinterpret_cast<const u32x4*>(pr), a1 = *reinterpret_cast<const u32x4*>(pr + 8);
-            uint32_t pk[8];
+            for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.0f / PK);
+            float ss = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t sw = (q < 4) ? a0[q & 3] : a1[q & 3];
-                const float xa = __builtin_bit_cast(float, sw << 16), xb = __builtin_bit_cast(float, sw & 0xffff0000u);
-                pk[q] = pack_bf16x2(v[2 * q] * gelu_erf_grad(xa), v[2 * q + 1] * gelu_erf_grad(xb));
-            }
-            bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
-            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-        } else {  // E_UNEMBED: n tile = patch pixel (i, j); features = base channel o
-            const TokPos t = token_of_row(m, p);
-            const int pix = n0 >> 6, i = pix >> 3, j = pix & 7;
-            const int py = t.ty * 8 + i, px = t.tx * 8 + j;
-            if (!t.valid || py >= p.H || px >= p.W) continue;
-            const size_t off = (((size_t)t.b * p.H + py) * p.W + px) * 64 + g * 16;
-            u32x4 s0 = {0u, 0u, 0u, 0u}, s1 = {0u, 0u, 0u, 0u};
-            if (p.skip) {
-                s0 = *reinterpret_cast<const u32x4*>(p.skip + off);
-                s1 = *reinterpret_cast<const u32x4*>(p.skip + off + 8);
-            }
-            uint32_t pk[8];
+            for (int q = 0; q < 3; ++q)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint32_t sw = (q < 4) ? s0[q & 3] : s1[q & 3];
-                const float sa = __builtin_bit_cast(float, sw << 16);
-                const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
-                pk[q] = pack_bf16x2(v[2 * q] + bvec[2 * q] + sa, v[2 * q + 1] + bvec[2 * q + 1] + sb);
+                for (int e = 0; e < 4; ++e) { const float d = v[q][e] - mean; ss += d * d; }
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+            const float rstd = rsqrtf(ss * (1.0f / PK) + 1e-5f);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (v[q][e] - mean) * rstd * gm[q][e] + bt[q][e];
+                *reinterpret_cast<u32x2*>(a_lds + q * (PBM * 128) + swz128(r, sub >> 1) + (sub & 1) * 8) =
+                    u32x2{pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3])};
             }
-            bf16_t* o = (bf16_t*)p.out + off;
-            *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-            *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        }
+    } else {
+#pragma unroll 4
+        for (int u = 0; u < 12; ++u) {
+            const int idx = tid + u * 256;                  // 3072 chunks of 8 elements: row = idx / 24
+            const int row = idx / 24, c = idx - row * 24;
+            const int m = min(m0 + row, p.M - 1);
+            u32x4 v;
+            if constexpr (AMODE == A_BF16) {
+                v = *reinterpret_cast<const u32x4*>((const bf16_t*)p.A + (size_t)m * p.lda + c * 8);
+            } else {
+                const float* src = (const float*)p.A + (size_t)m * p.lda + c * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+                v = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+            }
+            *reinterpret_cast<u32x4*>(a_lds + (c >> 3) * (PBM * 128) + swz128(row, c & 7)) = v;
         }
     }
+
+    const uint32_t a_tok0 = lds_addr(a_lds) + (uint32_t)swz128(32 * wave + pl, g);
+    const uint32_t a_tok1 = lds_addr(a_lds) + (uint32_t)swz128(32 * wave + 16 + pl, g);
+    const uint32_t w_frag = lds_addr(w_lds) + (uint32_t)swz128(pl, g);
+
+    for (int nt = 0; nt < ntiles; ++nt) {
+        store_w();
+        __syncthreads();                        // W tile nt (and, first time, the A tile) visible
+        if (nt + 1 < ntiles) load_w(nt + 1);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            bf16x8 tf[2][2], wf[2][4];
+            auto ld = [&](int step, int slot) {
+                const int kc = step >> 1;
+                const uint32_t khx = (step & 1) << 6;
+                tf[slot][0] = lds_read_b128_asm((a_tok0 ^ khx) + kc * (PBM * 128));
+                tf[slot][1] = lds_read_b128_asm((a_tok1 ^ khx) + kc * (PBM * 128));
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) wf[slot][ct] = lds_read_b128_asm((w_frag ^ khx) + kc * (64 * 128) + ct * 2048);
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int cur = step & 1;
+                if (step + 1 < 6) { ld(step + 1, cur ^ 1); lds_wait<6>(); } else { lds_wait<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = mfma16x16x32(wf[cur][ct], tf[cur][tg], acc[tg][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();                        // everyone done reading W tile nt
+        const int n0 = nt * 64;
+        float bvec[16];
+        gemm_load_bias(p, n0, g, EPI == E_UNEMBED, bvec);
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            const int m = m0 + 32 * wave + 16 * tg + pl;
+            if (m >= p.M) continue;
+            float v[16];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ct][e];
+            gemm_store_row<EPI>(p, m, n0, g, v, bvec);
+        }
+    }
+}
+
+template <int AMODE, int EPI>
+int launch_panel(const GemmParams& p, hipStream_t s)
+{
+    if (p.M <= 0) return 0;
+    if (p.N % 64 != 0 || p.K != PK) return (int)hipErrorInvalidValue;
+    constexpr size_t lds = PA_BYTES + PW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_panel_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    gemm_panel_kernel<AMODE, EPI><<<dim3((p.M + PBM - 1) / PBM), dim3(256), lds, s>>>(p);
+    TUP_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int AMODE, int EPI>
@@ -322,6 +504,19 @@ extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const vo
     if ((epilogue == 1 || epilogue == 2) && !bias) return (int)hipErrorInvalidValue;
     if (epilogue == 2 && !res) return (int)hipErrorInvalidValue;
     if (epilogue == 3 && !aux) return (int)hipErrorInvalidValue;
+    static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
+    if (K == PK && use_panel) {
+        if (a_dtype == 0) {
+            if (epilogue == 0) return launch_panel<A_BF16, E_BF16>(p, s);
+            if (epilogue == 1) return launch_panel<A_BF16, E_GELU_BF16>(p, s);
+            if (epilogue == 2) return launch_panel<A_BF16, E_RES_F32>(p, s);
+            if (epilogue == 3) return launch_panel<A_BF16, E_GELU_BWD>(p, s);
+        } else if (a_dtype == 1) {
+            if (epilogue == 0) return launch_panel<A_F32, E_BF16>(p, s);
+            if (epilogue == 3) return launch_panel<A_F32, E_GELU_BWD>(p, s);
+        }
+        return (int)hipErrorInvalidValue;
+    }
     if (a_dtype == 0) {
         if (epilogue == 0) return launch<A_BF16, E_BF16>(p, s);
         if (epilogue == 1) return launch<A_BF16, E_GELU_BF16>(p, s);
@@ -359,7 +554,20 @@ extern "C" int tup_patch_unembed_fwd(const float* x, const void* Wt, const float
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = x; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
+    static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
+    if (use_panel) return launch_panel<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// LayerNorm fused into a Linear (norm1 -> attn.qkv, model.py:163 + :115): out bf16 [M][N] = LN(x) Wt^T + bias.
+// x fp32 [M][192]; Wt bf16 [N][192] (rows permuted per 64-group).
+extern "C" int tup_ln_gemm_fwd(const float* x, const float* gamma, const float* beta, const void* Wt,
+                               const float* bias, void* out, int M, int N, void* stream)
+{
+    GemmParams p{};
+    p.A = x; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.ldo = N;
+    p.M = M; p.N = N; p.K = 192; p.ln_gamma = gamma; p.ln_beta = beta;
+    return launch_panel<A_LN, E_BF16>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Backward of patch_unembed w.r.t. its input tokens (model.py:292-305 under autograd): gather the 8x8

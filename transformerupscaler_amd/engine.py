@@ -48,8 +48,11 @@ fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); Fal
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     for i in range(BLOCKS):
-        y = ops.layernorm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"])
-        qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
+        if fuse_blocks:
+            qkv = ops.ln_gemm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"])
+        else:
+            y = ops.layernorm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"])
+            qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
         att = ops.window_attn(qkv, bias_frags[i])
         ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=x, out=x)
         if fuse_blocks:

@@ -175,6 +175,16 @@ def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None, drop_p=0.0,
     return out
 
 
+def ln_gemm(x, gamma, beta, wt, bias):
+    """bf16 [M][N] = LayerNorm(x) @ wt^T + bias (LN fused into the GEMM's A load)."""
+    M = x.shape[0]
+    N = wt.shape[0]
+    out = torch.empty((M, N), dtype=BF16, device=x.device)
+    _lib.call("tup_ln_gemm_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma, F32, (192,), "gamma"), _chk(beta, F32, (192,), "beta"),
+              _chk(wt, BF16, (N, 192), "wt"), _chk(bias, F32, (N,), "bias"), out.data_ptr(), M, N, _stream())
+    return out
+
+
 def fused_mlp(x, gamma, beta, w1, b1, w2, b2):
     """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip)."""
     M = x.shape[0]

@@ -70,6 +70,15 @@ int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, const int* y
                       int KY, const int* xmin, const int* xsize, const float* xw, int KX, int planes,
                       int Hi, int Wi, int Ho, int Wo, int clamp01, void* stream);
 
+/* Inference fusion of the output tail (model.py:316-327): last final_upscale stage (Conv2d(3,3rr,3)+PixelShuffle),
+ * final_upscale_conv, "+ upscaled_input", Resize (tap tables; identity tables when sizes match) and clamp.
+ * x fp32 [B][3][H][W]; ui fp32 [B][3][H*r][W*r]; out fp32 [B][3][Ho][Wo]; EH/EW = largest HR window a 16x64
+ * output tile's taps touch. */
+int tup_tail_fused_fwd(const float* x, const float* wfu, const float* bfu, const float* wfc, const float* bfc,
+                       const float* ui, float* out, const int* ymin, const int* ysize, const float* yw, int KY,
+                       const int* xmin, const int* xsize, const float* xw, int KX, int B, int H, int W, int r,
+                       int Ho, int Wo, int EH, int EW, int clamp01, void* stream);
+
 /* torch.clamp(out, 0, 1) model.py:327 when no resize precedes it. */
 int tup_clamp01_fwd(const float* in, float* out, long long n, void* stream);
 

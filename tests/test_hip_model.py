@@ -138,3 +138,24 @@ def test_batch_equals_per_sample(model):
         yb = model(x, upscale_factor=2)
         ys = torch.cat([model(x[i:i + 1], upscale_factor=2) for i in range(3)])
     assert torch.equal(yb, ys)
+
+
+@pytest.mark.parametrize("name", ["fwd_g36x48_resize54x72.npz", "fwd_g20x28_s4.npz", "fwd_g20x28_s6.npz", "fwd_g68x84_s2_b2.npz", "fwd_g24x40_res3.npz"])
+def test_fused_paths_equal_unfused(model, golden_dir, name):
+    """The inference fusions (composed branch A, LN+QKV, fused MLP, fused tail) against the one-kernel-per-op path."""
+    from transformerupscaler_amd import engine
+    d = dict(np.load(os.path.join(golden_dir, name)))
+    kw = {"require_ratio": bool(d["require_ratio"])}
+    if int(d["upscale_factor"]) > 0:
+        kw["upscale_factor"] = int(d["upscale_factor"])
+    else:
+        kw["res_out"] = tuple(int(v) for v in d["res_out"])
+    x = torch.from_numpy(d["x"]).cuda()
+    with torch.no_grad():
+        y_f = model(x, **kw).cpu()
+        engine.fuse_blocks, engine.fuse_tail = False, False
+        try:
+            y_u = model(x, **kw).cpu()
+        finally:
+            engine.fuse_blocks, engine.fuse_tail = True, True
+    assert (y_f - y_u).abs().max().item() <= 6e-3, (y_f - y_u).abs().max().item()

@@ -26,6 +26,7 @@ SIGNATURES = {
     "tup_conv5x5_c64_planar_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "tup_conv3x3_planar_fwd": [P, P, P, P, P, I, I, I, I, I, P],
     "tup_resize_aa_fwd": [P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P],
+    "tup_tail_fused_fwd": [P, P, P, P, P, P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "tup_clamp01_fwd": [P, P, c_longlong, P],
     "tup_layernorm_fwd": [P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand": [P, P, P],

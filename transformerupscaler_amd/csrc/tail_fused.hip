@@ -1,0 +1,167 @@
+// Fused output tail for inference (gfx950): the last final_upscale stage (Conv2d(3, 3rr, 3) + PixelShuffle(r)),
+// final_upscale_conv (Conv2d(3, 3, 3)), "+ upscaled_input", the antialiased Resize and the clamp
+// (reference models/FastTransformer/model.py:316-327, utils.py:62-63,74-75,83-84) as ONE kernel.
+//
+// All of it is 3-channel work: unfused it is four HBM round trips over HR-sized fp32 planes (t1, sum, out)
+// for ~170 MACs per pixel.  Here one workgroup owns a 16x64 tile of the FINAL image and walks the stencil
+// chain backwards through LDS: the HR window its resize taps touch (+1 halo for the 3x3), the LR window
+// under that (+1 halo) -- three small LDS tiles, three barriers, and HBM sees only the LR residual, the
+// upscaled_input plane and the output.  Bound: HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int OT_H = 16, OT_W = 64;
+
+struct TailParams {
+    const float* x;            // [B][3][H][W] input of the last final_upscale stage
+    const float* wfu;          // [3rr][28] (27 taps (cin, ky, kx) + pad)
+    const float* bfu;          // [3rr]
+    const float* wfc;          // [3][28]
+    const float* bfc;          // [3]
+    const float* ui;           // [B][3][H*r][W*r] upscaled_input (already ReLU'd)
+    float* out;                // [B][3][Ho][Wo]
+    const int* ymin; const int* ysize; const float* yw; int KY;
+    const int* xmin; const int* xsize; const float* xw; int KX;
+    int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01;
+};
+
+__global__ __launch_bounds__(256) void tail_fused_kernel(const TailParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float fl[];
+    const int r = p.r, rr = r * r, nfu = 3 * rr;
+    const int Hs = p.H * r, Ws = p.W * r;
+    const int TH1 = p.EH + 2, TW1 = p.EW + 2;            // t1 tile (sum window + 3x3 halo)
+    float* wfu = fl;                                    // [nfu][28]
+    float* bfu = wfu + nfu * 28;                        // [nfu]
+    float* wfc = bfu + nfu;                             // [3][28] + [3] bias at wfc[84..86]
+    float* lr = wfc + 88;                               // [3][LH][LW]
+    float* t1 = lr + 3 * p.LH * p.LW;                   // [3][TH1][TW1]
+    float* sm = t1 + 3 * TH1 * TW1;                     // [3][EH][EW]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int oy0 = blockIdx.y * OT_H, ox0 = blockIdx.x * OT_W;
+    const int oy1 = min(oy0 + OT_H, p.Ho) - 1, ox1 = min(ox0 + OT_W, p.Wo) - 1;
+    // HR window touched by this tile's resize taps (tables are monotone)
+    const int hy0 = p.ymin[oy0], hx0 = p.xmin[ox0];
+    const int eh = p.ymin[oy1] + p.ysize[oy1] - hy0, ew = p.xmin[ox1] + p.xsize[ox1] - hx0;
+    // LR window under the t1 tile [hy0-1, hy0+eh] x [hx0-1, hx0+ew] (clipped), plus the 3x3 halo
+    const int ly0 = max(hy0 - 1, 0) / r - 1, lx0 = max(hx0 - 1, 0) / r - 1;
+
+    for (int i = tid; i < nfu * 28; i += 256) wfu[i] = p.wfu[i];
+    for (int i = tid; i < nfu; i += 256) bfu[i] = p.bfu[i];
+    if (tid < 84) wfc[tid] = p.wfc[tid];
+    if (tid < 3) wfc[84 + tid] = p.bfc[tid];
+    // ---- stage A: LR window (zero outside the image = the conv's zero padding) ----
+    for (int i = tid; i < 3 * p.LH * p.LW; i += 256) {
+        const int c = i / (p.LH * p.LW), q = i - c * p.LH * p.LW;
+        const int yy = q / p.LW, xx = q - yy * p.LW;
+        const int iy = ly0 + yy, ix = lx0 + xx;
+        lr[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix] : 0.f;
+    }
+    __syncthreads();
+    // ---- stage B: t1 = PixelShuffle(conv3x3(x)) on the haloed HR window (zero outside the HR image) ----
+    const int th1 = eh + 2, tw1 = ew + 2;
+    for (int i = tid; i < th1 * tw1; i += 256) {
+        const int ty = i / tw1, tx = i - ty * tw1;
+        const int Y = hy0 - 1 + ty, X = hx0 - 1 + tx;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        if (Y >= 0 && Y < Hs && X >= 0 && X < Ws) {
+            const int y = Y / r, si = Y - y * r, x = X / r, sj = X - x * r;
+            const int sp = si * r + sj;
+            const float* w0 = wfu + (0 * rr + sp) * 28;
+            const float* w1 = wfu + (1 * rr + sp) * 28;
+            const float* w2 = wfu + (2 * rr + sp) * 28;
+            a0 = bfu[0 * rr + sp]; a1 = bfu[1 * rr + sp]; a2 = bfu[2 * rr + sp];
+            const float* base = lr + (y - 1 - ly0) * p.LW + (x - 1 - lx0);
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float v = base[ci * p.LH * p.LW + ky * p.LW + kx];
+                        const int k = ci * 9 + ky * 3 + kx;
+                        a0 = fmaf(w0[k], v, a0); a1 = fmaf(w1[k], v, a1); a2 = fmaf(w2[k], v, a2);
+                    }
+        }
+        t1[0 * TH1 * TW1 + ty * TW1 + tx] = a0;
+        t1[1 * TH1 * TW1 + ty * TW1 + tx] = a1;
+        t1[2 * TH1 * TW1 + ty * TW1 + tx] = a2;
+    }
+    __syncthreads();
+    // ---- stage C: sum = conv3x3(t1) + bias + upscaled_input on the HR window ----
+    for (int i = tid; i < eh * ew; i += 256) {
+        const int sy = i / ew, sx = i - sy * ew;
+        const int Y = hy0 + sy, X = hx0 + sx;             // always inside the HR image
+        float a0 = wfc[84], a1 = wfc[85], a2 = wfc[86];
+        const float* base = t1 + sy * TW1 + sx;           // t1 tile origin is (hy0-1, hx0-1)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = base[ci * TH1 * TW1 + ky * TW1 + kx];
+                    const int k = ci * 9 + ky * 3 + kx;
+                    a0 = fmaf(wfc[k], v, a0); a1 = fmaf(wfc[28 + k], v, a1); a2 = fmaf(wfc[56 + k], v, a2);
+                }
+        const size_t o = ((size_t)b * 3 * Hs + Y) * Ws + X;
+        sm[0 * p.EH * p.EW + sy * p.EW + sx] = a0 + p.ui[o];
+        sm[1 * p.EH * p.EW + sy * p.EW + sx] = a1 + p.ui[o + (size_t)Hs * Ws];
+        sm[2 * p.EH * p.EW + sy * p.EW + sx] = a2 + p.ui[o + 2 * (size_t)Hs * Ws];
+    }
+    __syncthreads();
+    // ---- stage D: antialiased resize taps + clamp ----
+    for (int i = tid; i < OT_H * OT_W; i += 256) {
+        const int oy = oy0 + i / OT_W, ox = ox0 + i % OT_W;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const int y0 = p.ymin[oy] - hy0, ny = p.ysize[oy], x0 = p.xmin[ox] - hx0, nx = p.xsize[ox];
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a) {
+            const float wy = p.yw[oy * p.KY + a];
+            float h[3] = {0.f, 0.f, 0.f};
+            for (int c2 = 0; c2 < nx; ++c2) {
+                const float wx = p.xw[ox * p.KX + c2];
+                const float* s0 = sm + (y0 + a) * p.EW + x0 + c2;
+                h[0] = fmaf(wx, s0[0], h[0]); h[1] = fmaf(wx, s0[p.EH * p.EW], h[1]); h[2] = fmaf(wx, s0[2 * p.EH * p.EW], h[2]);
+            }
+            acc[0] = fmaf(wy, h[0], acc[0]); acc[1] = fmaf(wy, h[1], acc[1]); acc[2] = fmaf(wy, h[2], acc[2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = acc[c];
+            if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+            p.out[(((size_t)b * 3 + c) * p.Ho + oy) * p.Wo + ox] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// x fp32 [B][3][H][W]; wfu fp32 [3rr][28], bfu [3rr]; wfc fp32 [3][28], bfc [3]; ui fp32 [B][3][H*r][W*r];
+// out fp32 [B][3][Ho][Wo].  Tap tables as tup_resize_aa_fwd (identity tables when Ho x Wo == H*r x W*r).
+// EH / EW: the largest HR window (rows / cols) any 16x64 output tile's taps touch (computed by the caller from
+// the same tables; they size the LDS tiles).
+extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float* bfu, const float* wfc, const float* bfc,
+                                  const float* ui, float* out, const int* ymin, const int* ysize, const float* yw, int KY,
+                                  const int* xmin, const int* xsize, const float* xw, int KX, int B, int H, int W, int r,
+                                  int Ho, int Wo, int EH, int EW, int clamp01, void* stream)
+{
+    if (B <= 0) return 0;
+    if (r < 1 || r > 6 || B > 65535 || EH < 1 || EW < 1) return (int)hipErrorInvalidValue;
+    TailParams p{};
+    p.x = x; p.wfu = wfu; p.bfu = bfu; p.wfc = wfc; p.bfc = bfc; p.ui = ui; p.out = out;
+    p.ymin = ymin; p.ysize = ysize; p.yw = yw; p.KY = KY; p.xmin = xmin; p.xsize = xsize; p.xw = xw; p.KX = KX;
+    p.H = H; p.W = W; p.r = r; p.Ho = Ho; p.Wo = Wo; p.EH = EH; p.EW = EW; p.clamp01 = clamp01;
+    p.LH = (EH + 2) / r + 4; p.LW = (EW + 2) / r + 4;
+    const int nfu = 3 * r * r;
+    const size_t lds = ((size_t)nfu * 29 + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW) * sizeof(float);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((Wo + OT_W - 1) / OT_W, (Ho + OT_H - 1) / OT_H, B);
+    tail_fused_kernel<<<grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

@@ -43,6 +43,7 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
 
 
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
+fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 
 
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
@@ -108,12 +109,21 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
     if cap is not None:
         cap["combined"] = combined; cap["dec"] = dec; cap["residual"] = residual
     t = residual
-    for si, (_, r) in enumerate(upsampler_layout(scale)):
-        t = ops.conv_planar(t, pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r)
     hs, ws = H * scale, W * scale
     # model.py:323: `res_out != (out.shape[2], out.shape[2])` -- the (H, H) quirk is kept; Resize to an
     # identical size is the identity.
     needs_resize = bool(require_ratio) and tuple(res_out) != (hs, hs) and tuple(res_out) != (hs, ws)
+    fu = upsampler_layout(scale)
+    if fuse_tail and cap is None:
+        for si, (_, r) in enumerate(fu[:-1]):
+            t = ops.conv_planar(t, pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r)
+        li = len(fu) - 1
+        with _stage("tail"):
+            out = ops.tail_fused(t, pk[f"fu.{li}.w"], pk[f"fu.{li}.b"], pk["fuc.w"], pk["fuc.b"], upscaled_input, fu[li][1],
+                                 tuple(res_out) if needs_resize else (hs, ws), clamp=True)
+        return out
+    for si, (_, r) in enumerate(fu):
+        t = ops.conv_planar(t, pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r)
     out = ops.conv_planar(t, pk["fuc.w"], pk["fuc.b"], 1, add=upscaled_input, clamp=not needs_resize)
     if cap is not None:
         cap["sum"] = out

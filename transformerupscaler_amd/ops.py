@@ -6,6 +6,7 @@ on the caller's current HIP stream.
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -113,6 +114,29 @@ def resize_aa(x, size, clamp=False):
     _lib.call("tup_resize_aa_fwd", _chk(x, F32, None, "x"), out.data_ptr(), ylo.data_ptr(), yn.data_ptr(),
               yw.data_ptr(), ky, xlo.data_ptr(), xn.data_ptr(), xw.data_ptr(), kx, B * C, Hi, Wi, Ho, Wo,
               int(clamp), _stream())
+    return out
+
+
+def tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True):
+    """Last final_upscale stage + final_upscale_conv + "+ upscaled_input" + Resize(out_hw) + clamp in one kernel."""
+    from .resize_taps import taps_or_identity, tile_extent
+    B, C, H, W = x.shape
+    Hs, Ws = H * r, W * r
+    Ho, Wo = out_hw
+    key = (str(x.device), "tail", Hs, Ws, Ho, Wo)
+    if key not in _TAP_CACHE:
+        ylo, yn, yw, ky = taps_or_identity(Hs, Ho)
+        xlo, xn, xw, kx = taps_or_identity(Ws, Wo)
+        d = x.device
+        _TAP_CACHE[key] = (torch.from_numpy(ylo).to(d), torch.from_numpy(yn).to(d), torch.from_numpy(np.ascontiguousarray(yw)).to(d), ky,
+                           torch.from_numpy(xlo).to(d), torch.from_numpy(xn).to(d), torch.from_numpy(np.ascontiguousarray(xw)).to(d), kx,
+                           tile_extent(Hs, Ho, 16), tile_extent(Ws, Wo, 64))
+    ylo, yn, yw, ky, xlo, xn, xw, kx, eh, ew = _TAP_CACHE[key]
+    out = torch.empty((B, 3, Ho, Wo), dtype=F32, device=x.device)
+    _lib.call("tup_tail_fused_fwd", _chk(x, F32, None, "x"), _chk(wfu, F32, (3 * r * r, 28), "wfu"), _chk(bfu, F32, (3 * r * r,), "bfu"),
+              _chk(wfc, F32, (3, 28), "wfc"), _chk(bfc, F32, (3,), "bfc"), _chk(ui, F32, (B, 3, Hs, Ws), "ui"), out.data_ptr(),
+              ylo.data_ptr(), yn.data_ptr(), yw.data_ptr(), ky, xlo.data_ptr(), xn.data_ptr(), xw.data_ptr(), kx,
+              B, H, W, r, Ho, Wo, eh, ew, int(clamp), _stream())
     return out
 
 

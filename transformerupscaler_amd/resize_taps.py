@@ -54,3 +54,22 @@ def aa_inverse_ranges(in_size: int, out_size: int):
         for o in range(int(o0[i]), int(o0[i] + on[i])):
             assert lo[o] <= i < lo[o] + n[o]
     return o0, on
+
+
+@functools.lru_cache(maxsize=64)
+def taps_or_identity(in_size: int, out_size: int):
+    """aa_taps, or exact identity tables when the sizes match (transforms.Resize returns its input then)."""
+    if in_size == out_size:
+        return (np.arange(out_size, dtype=np.int32), np.ones(out_size, np.int32), np.ones((out_size, 1), np.float32), 1)
+    return aa_taps(in_size, out_size)
+
+
+@functools.lru_cache(maxsize=64)
+def tile_extent(in_size: int, out_size: int, tile: int) -> int:
+    """Largest input window any `tile`-wide run of outputs touches (sizes the fused tail kernel's LDS tiles)."""
+    lo, n, _, _ = taps_or_identity(in_size, out_size)
+    best = 1
+    for o0 in range(0, out_size, tile):
+        o1 = min(o0 + tile, out_size) - 1
+        best = max(best, int(lo[o1] + n[o1] - lo[o0]))
+    return best

@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int OT_H = 16, OT_W = 64;
+constexpr int OT_H = 16, OT_W = 64, NT = 512, NROW = NT / 64;     // 8 waves per workgroup
 
 struct TailParams {
     const float* x;            // [B][3][H][W] input of the last final_upscale stage
@@ -26,7 +26,7 @@ struct TailParams {
     int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01;
 };
 
-__global__ __launch_bounds__(256) void tail_fused_kernel(const TailParams p)
+__global__ __launch_bounds__(NT) void tail_fused_kernel(const TailParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float fl[];
     const int r = p.r, rr = r * r, nfu = 3 * rr;
@@ -48,91 +48,124 @@ __global__ __launch_bounds__(256) void tail_fused_kernel(const TailParams p)
     // LR window under the t1 tile [hy0-1, hy0+eh] x [hx0-1, hx0+ew] (clipped), plus the 3x3 halo
     const int ly0 = max(hy0 - 1, 0) / r - 1, lx0 = max(hx0 - 1, 0) / r - 1;
 
-    for (int i = tid; i < nfu * 28; i += 256) wfu[i] = p.wfu[i];
-    for (int i = tid; i < nfu; i += 256) bfu[i] = p.bfu[i];
-    if (tid < 84) wfc[tid] = p.wfc[tid];
-    if (tid < 3) wfc[84 + tid] = p.bfc[tid];
+    for (int i = tid; i < nfu * 28; i += NT) wfu[i] = p.wfu[i];
+    for (int i = tid; i < nfu; i += NT) bfu[i] = p.bfu[i];
     // ---- stage A: LR window (zero outside the image = the conv's zero padding) ----
-    for (int i = tid; i < 3 * p.LH * p.LW; i += 256) {
-        const int c = i / (p.LH * p.LW), q = i - c * p.LH * p.LW;
-        const int yy = q / p.LW, xx = q - yy * p.LW;
-        const int iy = ly0 + yy, ix = lx0 + xx;
-        lr[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix] : 0.f;
+    // (all tile loops below are 2-D with power-of-two thread strides: runtime integer divisions cost ~40
+    //  instructions each and used to outweigh the arithmetic)
+    const int t_row = tid >> 6, t_col = tid & 63;
+    for (int c = 0; c < 3; ++c)
+        for (int yy = t_row; yy < p.LH; yy += NROW)
+            for (int xx = t_col; xx < p.LW; xx += 64) {
+                const int iy = ly0 + yy, ix = lx0 + xx;
+                lr[(c * p.LH + yy) * p.LW + xx] =
+                    (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix] : 0.f;
+            }
+    __syncthreads();
+    // ---- stage B: t1 = PixelShuffle(conv3x3(x)) on the haloed HR window (zero outside the HR image).
+    // A thread owns ONE sub-pixel phase (si, sj): its 81 weights live in registers and it walks LR pixels, so
+    // the inner loop is 27 LDS reads per 81 FMAs (weights from LDS per FMA made this stage LDS-issue bound). ----
+    for (int i = tid; i < 3 * TH1 * TW1; i += NT) t1[i] = 0.f;
+    __syncthreads();
+    {
+        const int nslots = NT / rr;
+        const int ph = tid % rr, slot = tid / rr;
+        if (slot < nslots) {
+            const int si = ph / r, sj = ph - si * r;
+            float w[3][27], bias3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                bias3[c] = bfu[c * rr + ph];
+#pragma unroll
+                for (int k = 0; k < 27; ++k) w[c][k] = wfu[(c * rr + ph) * 28 + k];
+            }
+            // LR pixels whose phase-(si,sj) child lies in the t1 window [hy0-1, hy0+eh] x [hx0-1, hx0+ew] and the image
+            const int Ya = max(hy0 - 1, 0), Yb = min(hy0 + eh, Hs - 1), Xa = max(hx0 - 1, 0), Xb = min(hx0 + ew, Ws - 1);
+            const int ya = (Ya - si + r - 1) / r, yb = (Yb - si >= 0) ? (Yb - si) / r : -1;
+            const int xa = (Xa - sj + r - 1) / r, xb = (Xb - sj >= 0) ? (Xb - sj) / r : -1;
+            const int scols = nslots >= 16 ? 16 : nslots, srows = nslots / scols;
+            const int s_row = slot / scols, s_col = slot - s_row * scols;
+            if (s_row < srows)
+            for (int y = ya + s_row; y <= yb; y += srows)
+            for (int x = xa + s_col; x <= xb; x += scols) {
+                const float* base = lr + (y - 1 - ly0) * p.LW + (x - 1 - lx0);
+                float a0 = bias3[0], a1 = bias3[1], a2 = bias3[2];
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float v = base[ci * p.LH * p.LW + ky * p.LW + kx];
+                            const int k = ci * 9 + ky * 3 + kx;
+                            a0 = fmaf(w[0][k], v, a0); a1 = fmaf(w[1][k], v, a1); a2 = fmaf(w[2][k], v, a2);
+                        }
+                const int ty = y * r + si - (hy0 - 1), tx = x * r + sj - (hx0 - 1);
+                t1[0 * TH1 * TW1 + ty * TW1 + tx] = a0;
+                t1[1 * TH1 * TW1 + ty * TW1 + tx] = a1;
+                t1[2 * TH1 * TW1 + ty * TW1 + tx] = a2;
+            }
+        }
     }
     __syncthreads();
-    // ---- stage B: t1 = PixelShuffle(conv3x3(x)) on the haloed HR window (zero outside the HR image) ----
-    const int th1 = eh + 2, tw1 = ew + 2;
-    for (int i = tid; i < th1 * tw1; i += 256) {
-        const int ty = i / tw1, tx = i - ty * tw1;
-        const int Y = hy0 - 1 + ty, X = hx0 - 1 + tx;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        if (Y >= 0 && Y < Hs && X >= 0 && X < Ws) {
-            const int y = Y / r, si = Y - y * r, x = X / r, sj = X - x * r;
-            const int sp = si * r + sj;
-            const float* w0 = wfu + (0 * rr + sp) * 28;
-            const float* w1 = wfu + (1 * rr + sp) * 28;
-            const float* w2 = wfu + (2 * rr + sp) * 28;
-            a0 = bfu[0 * rr + sp]; a1 = bfu[1 * rr + sp]; a2 = bfu[2 * rr + sp];
-            const float* base = lr + (y - 1 - ly0) * p.LW + (x - 1 - lx0);
+    // ---- stage C: sum = conv3x3(t1) + bias + upscaled_input on the HR window; the 81 weights are wave-uniform
+    // (scalar loads straight from the kernel argument), the t1 taps come from LDS ----
+    {
+        const float* __restrict__ wg = p.wfc;
+        const float b0 = p.bfc[0], b1 = p.bfc[1], b2 = p.bfc[2];
+        for (int sy = t_row; sy < eh; sy += NROW)
+        for (int sx = t_col; sx < ew; sx += 64) {
+            const int Y = hy0 + sy, X = hx0 + sx;             // always inside the HR image
+            float a0 = b0, a1 = b1, a2 = b2;
+            const float* base = t1 + sy * TW1 + sx;           // t1 tile origin is (hy0-1, hx0-1)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float v = base[ci * p.LH * p.LW + ky * p.LW + kx];
+                        const float v = base[ci * TH1 * TW1 + ky * TW1 + kx];
                         const int k = ci * 9 + ky * 3 + kx;
-                        a0 = fmaf(w0[k], v, a0); a1 = fmaf(w1[k], v, a1); a2 = fmaf(w2[k], v, a2);
+                        a0 = fmaf(wg[k], v, a0); a1 = fmaf(wg[28 + k], v, a1); a2 = fmaf(wg[56 + k], v, a2);
                     }
+            const size_t o = ((size_t)b * 3 * Hs + Y) * Ws + X;
+            sm[0 * p.EH * p.EW + sy * p.EW + sx] = a0 + p.ui[o];
+            sm[1 * p.EH * p.EW + sy * p.EW + sx] = a1 + p.ui[o + (size_t)Hs * Ws];
+            sm[2 * p.EH * p.EW + sy * p.EW + sx] = a2 + p.ui[o + 2 * (size_t)Hs * Ws];
         }
-        t1[0 * TH1 * TW1 + ty * TW1 + tx] = a0;
-        t1[1 * TH1 * TW1 + ty * TW1 + tx] = a1;
-        t1[2 * TH1 * TW1 + ty * TW1 + tx] = a2;
     }
     __syncthreads();
-    // ---- stage C: sum = conv3x3(t1) + bias + upscaled_input on the HR window ----
-    for (int i = tid; i < eh * ew; i += 256) {
-        const int sy = i / ew, sx = i - sy * ew;
-        const int Y = hy0 + sy, X = hx0 + sx;             // always inside the HR image
-        float a0 = wfc[84], a1 = wfc[85], a2 = wfc[86];
-        const float* base = t1 + sy * TW1 + sx;           // t1 tile origin is (hy0-1, hx0-1)
+    // ---- stage D: antialiased resize taps + clamp: a thread owns one output column (its x taps are loaded once) ----
+    {
+        const int ox = ox0 + t_col;
+        if (ox < p.Wo) {
+            const int x0 = p.xmin[ox] - hx0, nx = p.xsize[ox];
+            float wx[8];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
+            for (int j = 0; j < 8; ++j) wx[j] = (j < nx && j < p.KX) ? p.xw[ox * p.KX + j] : 0.f;
+            const int nxc = nx < 8 ? nx : 8;
+            for (int oy = oy0 + t_row; oy <= oy1; oy += NROW) {
+                const int y0 = p.ymin[oy] - hy0, ny = p.ysize[oy];
+                float acc[3] = {0.f, 0.f, 0.f};
+                for (int a = 0; a < ny; ++a) {
+                    const float wy = p.yw[oy * p.KY + a];
+                    float h[3] = {0.f, 0.f, 0.f};
+                    const float* s0 = sm + (y0 + a) * p.EW + x0;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float v = base[ci * TH1 * TW1 + ky * TW1 + kx];
-                    const int k = ci * 9 + ky * 3 + kx;
-                    a0 = fmaf(wfc[k], v, a0); a1 = fmaf(wfc[28 + k], v, a1); a2 = fmaf(wfc[56 + k], v, a2);
+                    for (int j = 0; j < 8; ++j)
+                        if (j < nxc) {
+                            h[0] = fmaf(wx[j], s0[j], h[0]); h[1] = fmaf(wx[j], s0[p.EH * p.EW + j], h[1]);
+                            h[2] = fmaf(wx[j], s0[2 * p.EH * p.EW + j], h[2]);
+                        }
+                    acc[0] = fmaf(wy, h[0], acc[0]); acc[1] = fmaf(wy, h[1], acc[1]); acc[2] = fmaf(wy, h[2], acc[2]);
                 }
-        const size_t o = ((size_t)b * 3 * Hs + Y) * Ws + X;
-        sm[0 * p.EH * p.EW + sy * p.EW + sx] = a0 + p.ui[o];
-        sm[1 * p.EH * p.EW + sy * p.EW + sx] = a1 + p.ui[o + (size_t)Hs * Ws];
-        sm[2 * p.EH * p.EW + sy * p.EW + sx] = a2 + p.ui[o + 2 * (size_t)Hs * Ws];
-    }
-    __syncthreads();
-    // ---- stage D: antialiased resize taps + clamp ----
-    for (int i = tid; i < OT_H * OT_W; i += 256) {
-        const int oy = oy0 + i / OT_W, ox = ox0 + i % OT_W;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const int y0 = p.ymin[oy] - hy0, ny = p.ysize[oy], x0 = p.xmin[ox] - hx0, nx = p.xsize[ox];
-        float acc[3] = {0.f, 0.f, 0.f};
-        for (int a = 0; a < ny; ++a) {
-            const float wy = p.yw[oy * p.KY + a];
-            float h[3] = {0.f, 0.f, 0.f};
-            for (int c2 = 0; c2 < nx; ++c2) {
-                const float wx = p.xw[ox * p.KX + c2];
-                const float* s0 = sm + (y0 + a) * p.EW + x0 + c2;
-                h[0] = fmaf(wx, s0[0], h[0]); h[1] = fmaf(wx, s0[p.EH * p.EW], h[1]); h[2] = fmaf(wx, s0[2 * p.EH * p.EW], h[2]);
-            }
-            acc[0] = fmaf(wy, h[0], acc[0]); acc[1] = fmaf(wy, h[1], acc[1]); acc[2] = fmaf(wy, h[2], acc[2]);
-        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = acc[c];
-            if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-            p.out[(((size_t)b * 3 + c) * p.Ho + oy) * p.Wo + ox] = v;
+                for (int c = 0; c < 3; ++c) {
+                    float v = acc[c];
+                    if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+                    p.out[(((size_t)b * 3 + c) * p.Ho + oy) * p.Wo + ox] = v;
+                }
+            }
         }
     }
 }
@@ -149,7 +182,7 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
                                   int Ho, int Wo, int EH, int EW, int clamp01, void* stream)
 {
     if (B <= 0) return 0;
-    if (r < 1 || r > 6 || B > 65535 || EH < 1 || EW < 1) return (int)hipErrorInvalidValue;
+    if (r < 1 || r > 6 || B > 65535 || EH < 1 || EW < 1 || KX > 8) return (int)hipErrorInvalidValue;
     TailParams p{};
     p.x = x; p.wfu = wfu; p.bfu = bfu; p.wfc = wfc; p.bfc = bfc; p.ui = ui; p.out = out;
     p.ymin = ymin; p.ysize = ysize; p.yw = yw; p.KY = KY; p.xmin = xmin; p.xsize = xsize; p.xw = xw; p.KX = KX;
@@ -161,7 +194,7 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     dim3 grid((Wo + OT_W - 1) / OT_W, (Ho + OT_H - 1) / OT_H, B);
-    tail_fused_kernel<<<grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
+    tail_fused_kernel<<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -220,18 +220,22 @@ __global__ __launch_bounds__(256, (CT <= 4 && KS == 3) ? 2 : 1) void conv3x3_c64
 
 
 // ------------------------------------------------------------------------------------------------
-// Persistent variant (single input chunk, in_r = 1): one workgroup per CU walks the pixel tiles.
+// Persistent ping-pong variant (single input chunk, in_r = 1): one 8-wave workgroup per CU walks the
+// pixel tiles.
 //   * all NTAPS weight slabs of the current cout tile stay resident in LDS (73.7 KB for 3x3 / 64 couts),
-//     so a tile is NTAPS*2 MFMA K-steps with no barrier in between;
-//   * the next tile's halo image is fetched with LDS-DMA (global_load_lds_dwordx4, per-lane source
-//     address carries the XOR swizzle and the halo clipping; out-of-image lanes read a zero line)
-//     into the second input buffer while the current tile computes: one barrier per tile.
+//     so a tile is NTAPS*2 MFMA K-steps with no barrier in between (fragment reads hand-pipelined);
+//   * the two wave groups (waves 0-3 / 4-7, one wave of each per SIMD) own one input buffer each and run
+//     half a period apart: while group A issues the K loop of its tile, group B converts / stores its
+//     previous tile and DMA-fetches its next halo image (global_load_lds_dwordx4; per-lane source address
+//     carries the XOR swizzle and the halo clipping, out-of-image lanes read a zero line), then they swap.
+//     The MFMA pipe of every SIMD always has one wave in a K loop; epilogue VALU, stores and DMA issue --
+//     40 % of the time when a single group did everything in sequence -- hide under it.
 // LDS: 9*8 KB + 2*43.5 KB = 160,768 B of the CU's 163,840 B.
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned int tup_zero_line[4] = {0u, 0u, 0u, 0u};
 
 template <int CT, int OUT_MODE, int KS>
-__global__ __launch_bounds__(256, 1) void conv_c64_persistent_kernel(
+__global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ add, const bf16_t* __restrict__ mask,
     void* __restrict__ out, int B, int H, int W, int ntiles, int r, int cout_valid, int relu,
@@ -243,20 +247,21 @@ __global__ __launch_bounds__(256, 1) void conv_c64_persistent_kernel(
     constexpr int WROWS = CT * 16, WSLAB = WROWS * 128, WCHUNKS = NTAPS * WROWS * 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w_lds = smem;                              // [NTAPS][WROWS][128 B]
-    char* in_lds = smem + NTAPS * WSLAB;             // [2][IN_BYTES]
+    char* in_lds = smem + NTAPS * WSLAB;             // [2 groups][IN_BYTES]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = threadIdx.x >> 8;                // wave group 0 / 1
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // indices inside the group
     const int g = lane >> 4, p = lane & 15;
     const int total_tiles = tilesX * tilesY * B;
+    char* my_in = in_lds + grp * IN_BYTES;
 
-    auto prefetch_tile = [&](int tile, int buf) {
+    auto prefetch_tile = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
         const int ty = t % tilesY;
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
-        const bf16_t* xb = x + (size_t)b * H * W * 64;
-        char* dst = in_lds + buf * IN_BYTES;
+        const char* xb = reinterpret_cast<const char*>(x + (size_t)b * H * W * 64);
 #pragma unroll 1
         for (int base = 0; base < IN_CHUNKS; base += 256) {
             const int idx = base + tid;                     // physical 16-B chunk of the LDS image
@@ -266,43 +271,139 @@ __global__ __launch_bounds__(256, 1) void conv_c64_persistent_kernel(
                 const int yy = q / HALO_W, xx = q - yy * HALO_W;
                 const int iy = ty0 - PADK + yy, ix = tx0 - PADK + xx;
                 const void* src = (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                                      ? (const void*)(xb + ((size_t)iy * W + ix) * 64 + c * 8) : (const void*)tup_zero_line;
+                                      ? (const void*)(xb + ((size_t)(iy * W + ix) * 128 + c * 16)) : (const void*)tup_zero_line;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dst + (base + wave * 64) * 16), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(my_in + (base + wave * 64) * 16), 16, 0, 0);
             }
         }
     };
     auto stage_weights = [&](int nt) {
         const bf16_t* wsrc = wp + (size_t)nt * NTAPS * WROWS * 64;
-        for (int idx = tid; idx < WCHUNKS; idx += 256) {
+        for (int idx = threadIdx.x; idx < WCHUNKS; idx += 512) {
             const int row = idx >> 3, c = idx & 7;             // row = tap*WROWS + n_local
             *reinterpret_cast<u32x4*>(w_lds + swz128(row, c)) = *reinterpret_cast<const u32x4*>(wsrc + (size_t)idx * 8);
         }
     };
 
-    int qb[4];
-#pragma unroll
-    for (int pg = 0; pg < 4; ++pg) qb[pg] = (2 * wave + (pg >> 1)) * HALO_W + (pg & 1) * 16 + p;
-
-    // loop-invariant LDS byte offsets of this lane's fragments (kh = 0): pixel fragments per (tap, pixel group)
-    // relative to the input buffer, weight fragments relative to slab row 0
+    // loop-invariant LDS byte offsets of this lane's fragments (kh = 0; kh = 1 is "^ 64")
     uint32_t poff[NTAPS][4];
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) poff[tap][pg] = (uint32_t)swz128(qb[pg] + (tap / KS) * HALO_W + (tap % KS), g);
+        for (int pg = 0; pg < 4; ++pg)
+            poff[tap][pg] = (uint32_t)swz128((2 * wave + (pg >> 1)) * HALO_W + (pg & 1) * 16 + p + (tap / KS) * HALO_W + (tap % KS), g);
     const uint32_t wbase = lds_addr(w_lds) + (uint32_t)swz128(p, g);
+    const uint32_t ibase = lds_addr(my_in);
 
-    int buf = 0;
-    if ((int)blockIdx.x < total_tiles) prefetch_tile(blockIdx.x, 0);
+    f32x4 acc[4][CT];
+    auto compute_tile = [&]() {
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NSTEPS = NTAPS * 2;
+        bf16x8 pf[2][4], wf[2][CT];
+        auto load_frags = [&](int step, int slot) {
+            const int tap = step >> 1;
+            const uint32_t khx = (step & 1) << 6;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) pf[slot][pg] = lds_read_b128_asm(ibase + (poff[tap][pg] ^ khx));
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wf[slot][ct] = lds_read_b128_asm((wbase ^ khx) + (tap * WROWS + ct * 16) * 128);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int step = 0; step < NSTEPS; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < NSTEPS) { load_frags(step + 1, cur ^ 1); lds_wait<4 + CT>(); } else { lds_wait<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = mfma16x16x32(wf[cur][ct], pf[cur][pg], acc[pg][ct]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4 bv[CT];
+    auto store_tile = [&](int tile, int nt) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            const int oy = ty * TH + 2 * wave + (pg >> 1);
+            const int ox = tx * TW + (pg & 1) * 16 + p;
+            if (oy >= H || ox >= W) continue;
+            if constexpr (OUT_MODE == OUT_NHWC_BF16) {
+                const int si = nt / r, sj = nt - si * r;
+                const int Hr = H * r, Wr = W * r;
+                const size_t eoff = (((size_t)b * Hr + (oy * r + si)) * Wr + (ox * r + sj)) * 64 + g * 16;
+                uint32_t pk[8], aw[8], mw[8];
+                if (add) {
+                    const u32x4 a0 = *reinterpret_cast<const u32x4*>(add + eoff), a1 = *reinterpret_cast<const u32x4*>(add + eoff + 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { aw[q] = a0[q]; aw[4 + q] = a1[q]; }
+                }
+                if (mask) {
+                    const u32x4 m0 = *reinterpret_cast<const u32x4*>(mask + eoff), m1 = *reinterpret_cast<const u32x4*>(mask + eoff + 8);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[pg][ct][e] + bv[ct][e];
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                        const int wi = (ct * 4 + e) >> 1;
+                        if (add) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
+                        if (mask) {
+                            const float mv = __builtin_bit_cast(float, (e & 1) ? (mw[wi] & 0xffff0000u) : (mw[wi] << 16));
+                            if (!(mv > 0.f)) v[e] = 0.f;
+                        }
+                    }
+                    pk[ct * 2 + 0] = pack_bf16x2(v[0], v[1]);
+                    pk[ct * 2 + 1] = pack_bf16x2(v[2], v[3]);
+                }
+                if constexpr (CT == 4) {
+                    bf16_t* o = reinterpret_cast<bf16_t*>(out) + eoff;
+                    *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                    *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+                }
+            } else {
+                float* o = reinterpret_cast<float*>(out);
+                const int rr = r * r, cimg = cout_valid / rr, Hr = H * r, Wr = W * r;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = 16 * ct + 4 * g + e;
+                        if (co < cout_valid) {
+                            float v = acc[pg][ct][e] + bv[ct][e];
+                            if (relu) v = fmaxf(v, 0.f);
+                            const int c = co / rr, sp = co - c * rr;
+                            const int si = sp / r, sj = sp - si * r;
+                            o[(((size_t)b * cimg + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] = v;
+                        }
+                    }
+            }
+        }
+    };
+
+    // tiles of this workgroup: blockIdx.x + k*gridDim.x; group `grp` takes k = grp, grp + 2, ...
+    const int stride = 2 * gridDim.x;
+    const int first = blockIdx.x + grp * gridDim.x;
+    const int my_count = first < total_tiles ? (total_tiles - first + stride - 1) / stride : 0;
+    const int cnt0 = (int)blockIdx.x < total_tiles ? (total_tiles - (int)blockIdx.x + stride - 1) / stride : 0;   // group 0's count >= group 1's
+    const int nphases = 2 * cnt0 + 1;               // uniform for the whole workgroup
+
     for (int nt = 0; nt < ntiles; ++nt) {
         stage_weights(nt);
-        // bias of this lane's output channels, loaded once per cout tile (an ordinary load issued while an
-        // LDS-DMA is in flight makes hipcc wait vmcnt(0) right there -- 16 of them per pixel group in the
-        // epilogue cost more than the whole K loop)
-        f32x4 bv[CT];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
+        for (int ct = 0; ct < CT; ++ct) {            // bias of this lane's output channels, once per cout tile
             bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (bias) {
                 if constexpr (OUT_MODE == OUT_NHWC_BF16) bv[ct] = *reinterpret_cast<const f32x4*>(bias + nt * 64 + g * 16 + ct * 4);
@@ -312,121 +413,24 @@ __global__ __launch_bounds__(256, 1) void conv_c64_persistent_kernel(
                 }
             }
         }
-        __syncthreads();            // weights visible; the compiler's vmcnt(0) here also retires the pending tile DMA
-        for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-            // next tile of this pass, or the first tile of the next pass (input tiles do not depend on nt)
-            int nxt = tile + gridDim.x;
-            if (nxt >= total_tiles) nxt = (nt + 1 < ntiles) ? (int)blockIdx.x : -1;
-            if (nxt >= 0) prefetch_tile(nxt, buf ^ 1);
+        if (grp == 0 && my_count > 0) prefetch_tile(first);
+        __syncthreads();            // weights + group 0's first tile visible (the barrier's vmcnt(0) retires the DMA)
 
-            f32x4 acc[4][CT];
-#pragma unroll
-            for (int pg = 0; pg < 4; ++pg)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // K loop: NTAPS*2 steps of 32 channels, software-pipelined by hand: the fragments of step k+1 are
-            // requested before the MFMAs of step k issue (one wave per SIMD: nothing else hides LDS latency).
-            // The reads are inline-asm ds_read_b128 with a hand-counted s_waitcnt lgkmcnt(4+CT): hipcc's own
-            // waitcnt pass only ever emits lgkmcnt(0) here (it sinks reads to their first use otherwise), which
-            // would drain the reads just issued.  sched_barrier(0) keeps the MFMAs below the wait (guide 5.4 r18).
-            constexpr int NSTEPS = NTAPS * 2;
-            const uint32_t ibase = lds_addr(in_lds) + buf * IN_BYTES;
-            bf16x8 pf[2][4], wf[2][CT];
-            auto load_frags = [&](int step, int slot) {
-                const int tap = step >> 1;
-                const uint32_t khx = (step & 1) << 6;              // kh toggles chunk bit 2 = byte-offset bit 6
-#pragma unroll
-                for (int pg = 0; pg < 4; ++pg) pf[slot][pg] = lds_read_b128_asm(ibase + (poff[tap][pg] ^ khx));
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) wf[slot][ct] = lds_read_b128_asm((wbase ^ khx) + (tap * WROWS + ct * 16) * 128);
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int step = 0; step < NSTEPS; ++step) {
-                const int cur = step & 1;
-                if (step + 1 < NSTEPS) {
-                    load_frags(step + 1, cur ^ 1);
-                    lds_wait<4 + CT>();                            // step k's fragments have landed
-                } else {
-                    lds_wait<0>();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pg = 0; pg < 4; ++pg)
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = mfma16x16x32(wf[cur][ct], pf[cur][pg], acc[pg][ct]);
-                __builtin_amdgcn_sched_barrier(0);
+        // phase ph: group (ph & 1) runs the K loop of its tile k = ph >> 1; the other group stores its previous
+        // tile and DMA-fetches its next one into its (now idle) buffer.  One workgroup barrier per phase.
+        for (int ph = 0; ph < nphases; ++ph) {
+            const int k = ph >> 1;
+            if ((ph & 1) == grp) {
+                if (k < my_count) compute_tile();
+            } else {
+                // group 0 is here on odd phases (just computed tile k, next is k+1); group 1 on even phases
+                // (computed tile k-1 in phase ph-1, next is k)
+                const int done = grp == 0 ? k : k - 1;
+                if (done >= 0 && done < my_count) store_tile(first + done * stride, nt);
+                const int nxt = done + 1;
+                if (nxt < my_count) prefetch_tile(first + nxt * stride);
             }
-
-            // ---- epilogue (same formats as conv3x3_c64_kernel) ----
-            int t = tile;
-            const int tx = t % tilesX; t /= tilesX;
-            const int ty = t % tilesY;
-            const int b = t / tilesY;
-#pragma unroll
-            for (int pg = 0; pg < 4; ++pg) {
-                const int oy = ty * TH + 2 * wave + (pg >> 1);
-                const int ox = tx * TW + (pg & 1) * 16 + p;
-                if (oy >= H || ox >= W) continue;
-                if constexpr (OUT_MODE == OUT_NHWC_BF16) {
-                    const int si = nt / r, sj = nt - si * r;
-                    const int Hr = H * r, Wr = W * r;
-                    const size_t eoff = (((size_t)b * Hr + (oy * r + si)) * Wr + (ox * r + sj)) * 64 + g * 16;
-                    uint32_t pk[8], aw[8], mw[8];
-                    if (add) {
-                        const u32x4 a0 = *reinterpret_cast<const u32x4*>(add + eoff), a1 = *reinterpret_cast<const u32x4*>(add + eoff + 8);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { aw[q] = a0[q]; aw[4 + q] = a1[q]; }
-                    }
-                    if (mask) {
-                        const u32x4 m0 = *reinterpret_cast<const u32x4*>(mask + eoff), m1 = *reinterpret_cast<const u32x4*>(mask + eoff + 8);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
-                    }
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[pg][ct][e];
-                            v[e] += bv[ct][e];
-                            if (relu) v[e] = fmaxf(v[e], 0.f);
-                            const int wi = (ct * 4 + e) >> 1;
-                            if (add) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
-                            if (mask) {
-                                const float mv = __builtin_bit_cast(float, (e & 1) ? (mw[wi] & 0xffff0000u) : (mw[wi] << 16));
-                                if (!(mv > 0.f)) v[e] = 0.f;
-                            }
-                        }
-                        pk[ct * 2 + 0] = pack_bf16x2(v[0], v[1]);
-                        pk[ct * 2 + 1] = pack_bf16x2(v[2], v[3]);
-                    }
-                    if constexpr (CT == 4) {
-                        bf16_t* o = reinterpret_cast<bf16_t*>(out) + eoff;
-                        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-                        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-                    }
-                } else {
-                    float* o = reinterpret_cast<float*>(out);
-                    const int rr = r * r, cimg = cout_valid / rr, Hr = H * r, Wr = W * r;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int co = 16 * ct + 4 * g + e;
-                            if (co < cout_valid) {
-                                float v = acc[pg][ct][e];
-                                v += bv[ct][e];
-                                if (relu) v = fmaxf(v, 0.f);
-                                const int c = co / rr, sp = co - c * rr;
-                                const int si = sp / r, sj = sp - si * r;
-                                o[(((size_t)b * cimg + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] = v;
-                            }
-                        }
-                }
-            }
-            __syncthreads();        // (+ vmcnt(0)) next tile's DMA has landed, everyone is done reading `buf`
-            buf ^= 1;
+            __syncthreads();
         }
     }
 }
@@ -449,7 +453,7 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
-    conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(256), lds, s>>>(
+    conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(512), lds, s>>>(
         (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, B, H, W, ntiles, r,
         cout_valid, relu, tilesX, tilesY);
     TUP_CHECK_LAUNCH();

@@ -1,0 +1,43 @@
+"""Worker for tests/test_hip_dp.py: python _dp_gpu_worker.py RANK WORLD PORT OUTFILE.
+Both ranks share cuda:0 (one-GPU box), so the collective runs over gloo; the reducer, bucketing and
+backward-overlap logic are the ones the RCCL path uses."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from transformerupscaler_amd.autograd import resize_aa
+    from transformerupscaler_amd.dp import DataParallel
+    from transformerupscaler_amd.weights import deterministic_state_dict
+    d = dict(np.load(os.path.join(ROOT, "tests", "golden", "train_g36x44.npz")))
+    model = importlib.import_module("models.FastTransformer.model").TransformerModel()
+    model.load_state_dict(deterministic_state_dict(0), strict=False)
+    model = model.cuda().eval()
+    DataParallel(model, scale=2, bucket_mb=2.0)
+    lr = torch.from_numpy(d["lr"])[rank:rank + 1].cuda()           # one sample per rank
+    hr = torch.from_numpy(d["hr"])[rank:rank + 1].cuda()
+    out = resize_aa(model(lr, res_out=(54, 66), require_ratio=False), (54, 66))
+    R = torch.rand((2, 3, 54, 66), generator=torch.Generator().manual_seed(5))[rank:rank + 1].cuda() - 0.5
+    (out * R).sum().backward()
+    if rank == 0:
+        torch.save({k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}, outfile)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"RANK{rank} OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256, (CT <= 4 && KS == 3) ? 2 : 1) void conv3x3_c64
 // LDS: 9*8 KB + 2*43.5 KB = 160,768 B of the CU's 163,840 B.
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) unsigned int tup_zero_line[4] = {0u, 0u, 0u, 0u};
+// Store sink for lanes whose pixel is outside the image: keeps the number of store instructions per wave
+// fixed (the counted vmcnt below relies on it); never read.
+__device__ __attribute__((aligned(16))) unsigned int tup_store_sink[64 * 8];
 
 template <int CT, int OUT_MODE, int KS>
 __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
@@ -335,18 +338,18 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         for (int pg = 0; pg < 4; ++pg) {
             const int oy = ty * TH + 2 * wave + (pg >> 1);
             const int ox = tx * TW + (pg & 1) * 16 + p;
-            if (oy >= H || ox >= W) continue;
+            const bool ok = oy < H && ox < W;
             if constexpr (OUT_MODE == OUT_NHWC_BF16) {
                 const int si = nt / r, sj = nt - si * r;
                 const int Hr = H * r, Wr = W * r;
                 const size_t eoff = (((size_t)b * Hr + (oy * r + si)) * Wr + (ox * r + sj)) * 64 + g * 16;
                 uint32_t pk[8], aw[8], mw[8];
-                if (add) {
+                if (add && ok) {
                     const u32x4 a0 = *reinterpret_cast<const u32x4*>(add + eoff), a1 = *reinterpret_cast<const u32x4*>(add + eoff + 8);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { aw[q] = a0[q]; aw[4 + q] = a1[q]; }
                 }
-                if (mask) {
+                if (mask && ok) {
                     const u32x4 m0 = *reinterpret_cast<const u32x4*>(mask + eoff), m1 = *reinterpret_cast<const u32x4*>(mask + eoff + 8);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                         v[e] = acc[pg][ct][e] + bv[ct][e];
                         if (relu) v[e] = fmaxf(v[e], 0.f);
                         const int wi = (ct * 4 + e) >> 1;
-                        if (add) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
-                        if (mask) {
+                        if (add && ok) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
+                        if (mask && ok) {
                             const float mv = __builtin_bit_cast(float, (e & 1) ? (mw[wi] & 0xffff0000u) : (mw[wi] << 16));
                             if (!(mv > 0.f)) v[e] = 0.f;
                         }
@@ -369,11 +372,13 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                     pk[ct * 2 + 1] = pack_bf16x2(v[2], v[3]);
                 }
                 if constexpr (CT == 4) {
-                    bf16_t* o = reinterpret_cast<bf16_t*>(out) + eoff;
+                    // exactly two store instructions per pixel group for every wave (out-of-image lanes hit the sink)
+                    bf16_t* o = ok ? reinterpret_cast<bf16_t*>(out) + eoff : reinterpret_cast<bf16_t*>(tup_store_sink) + lane * 16;
                     *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
                     *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
                 }
             } else {
+                if (!ok) continue;
                 float* o = reinterpret_cast<float*>(out);
                 const int rr = r * r, cimg = cout_valid / rr, Hr = H * r, Wr = W * r;
 #pragma unroll
@@ -426,12 +431,28 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 // group 0 is here on odd phases (just computed tile k, next is k+1); group 1 on even phases
                 // (computed tile k-1 in phase ph-1, next is k)
                 const int done = grp == 0 ? k : k - 1;
-                if (done >= 0 && done < my_count) store_tile(first + done * stride, nt);
                 const int nxt = done + 1;
+                // DMA first: it then has the whole phase (the other group's K loop) to land; the buffer is idle
+                // because this group's own K loop ended before the last barrier
                 if (nxt < my_count) prefetch_tile(first + nxt * stride);
+                if (done >= 0 && done < my_count) {
+                    store_tile(first + done * stride, nt);
+                    // The DMA (issued first) must have landed before the barrier; the 8 stores issued after it need
+                    // not: vmcnt counts in issue order, so "all but the youngest 8" = the DMA.  (A __syncthreads()
+                    // here makes hipcc wait vmcnt(0), i.e. for the stores' write latency, which was the longest
+                    // item of the phase.)
+                    if constexpr (OUT_MODE == OUT_NHWC_BF16 && CT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
+        // drain before the next pass restages the weights / the kernel ends
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 }
 

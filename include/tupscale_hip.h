@@ -132,6 +132,35 @@ int tup_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, con
                           void* out, int B, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * ResidualTransformer path (reference models/ResidualTransformer/model.py; forward / inference).
+ * Reuses conv1/conv2/decoder kernels above; the stride-2 `downsample` conv (model.py:89,132) runs on
+ * tup_conv3x3_c64_fwd with in_r = 2 (space-to-depth read) and a zero-padded 3x3x4 weight pack.
+ * ------------------------------------------------------------------------------------------- */
+
+/* patch_embed Conv2d(64,128,k8,s8) + flatten/transpose + pos_embed (model.py:135-140): feat bf16 NHWC
+ * [B][H][W][64]; Wt bf16 [128][4096]; pos fp32 [T][128]; x_out fp32 [B*T][128], T = (H/8)*(W/8). */
+int tup_rt_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, const float* pos, float* x_out,
+                           int B, int H, int W, void* stream);
+
+/* transpose/view + patch_unembed ConvTranspose2d(128,64,k8,s8) + skip add (model.py:147-153). */
+int tup_rt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip, void* out,
+                             int B, int H, int W, void* stream);
+
+/* nn.MultiheadAttention(128, 8 heads) core, eval mode (model.py:31,43): qkv bf16 [B][N][384] -> out bf16 [B][N][128];
+ * flash-style (online softmax), any N. */
+int tup_rt_attention_fwd(const void* qkv, void* out, int B, int N, void* stream);
+
+/* nn.LayerNorm(128) (model.py:30,32): x fp32 [M][128] -> y bf16. */
+int tup_layernorm128_fwd(const float* x, const float* gamma, const float* beta, void* y, int M, void* stream);
+
+/* out = clamp(F.interpolate(a, bicubic) + F.interpolate(b, bicubic)) (model.py:125,160-164); tables [Ho][4]/[Wo][4]
+ * of clamped source indices and weights per source (align_corners=False, A=-0.75). */
+int tup_rt_bicubic_sum_fwd(const float* a, const float* b, float* out, const int* ayi, const float* ayw,
+                           const int* axi, const float* axw, const int* byi, const float* byw, const int* bxi,
+                           const float* bxw, int planes, int Ha, int Wa, int Hb, int Wb, int Ho, int Wo,
+                           int clamp01, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Backward (what torch autograd executes for the same call sites under train.py:138).
  * Accumulating outputs (documented per function) must be zeroed by the caller.
  * ------------------------------------------------------------------------------------------- */

@@ -1,0 +1,91 @@
+"""ResidualTransformer (BASELINE.json config 5 geometry) on the MI355X: RT-specific kernels against torch, and the
+plugin module against the reference-generated fixtures (tests/golden/rt_fwd_*.npz) and the oracle."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import residual_transformer_oracle as R
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def rnd(shape, seed, scale=1.0, shift=0.0):
+    return (torch.rand(shape, generator=torch.Generator().manual_seed(seed)) * 2 - 1) * scale + shift
+
+
+def test_strided_conv_via_space_to_depth():
+    from transformerupscaler_amd import ops, packing
+    x = bf(rnd((2, 64, 36, 80), 1))
+    w, b = rnd((64, 64, 3, 3), 2, 0.06), rnd((64,), 3, 0.2)
+    ref = F.conv2d(x, bf(w), b, stride=2, padding=1).permute(0, 2, 3, 1)
+    wp, bp = packing.pack_conv_c64_stride2(w, b)
+    got = ops.conv_c64(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).cuda(), wp.cuda(), bp.cuda(), 1, relu=False, in_r=2)
+    assert tuple(got.shape) == (2, 18, 40, 64)
+    assert (got.float().cpu() - ref).abs().max() <= 1.5e-2 + 1e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("B,N", [(1, 3600), (2, 200), (1, 64)])
+def test_rt_attention(B, N):
+    from transformerupscaler_amd import ops
+    qkv = bf(rnd((B, N, 384), 4, 1.5))
+    q, k, v = qkv.view(B, N, 3, 8, 16).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((q * 0.25) @ k.transpose(-2, -1), -1) @ v).transpose(1, 2).reshape(B * N, 128)
+    got = ops.rt_attention(qkv.view(B * N, 384).to(torch.bfloat16).cuda(), B, N).float().cpu()
+    assert (got - ref).abs().max() <= 1.5e-2, (got - ref).abs().max()
+
+
+def test_layernorm128_and_bicubic():
+    from transformerupscaler_amd import ops
+    x = rnd((100, 128), 5, 2.0, 0.3)
+    gm, bt = rnd((128,), 6, 0.1, 1.0), rnd((128,), 7, 0.1)
+    got = ops.layernorm128(x.cuda(), gm.cuda(), bt.cuda()).float().cpu()
+    assert (got - F.layer_norm(x, (128,), gm, bt, 1e-5)).abs().max() <= 2e-2
+    a, b = rnd((2, 3, 36, 64), 8, 0.5, 0.5), rnd((2, 3, 18, 32), 9, 0.5)
+    for size in ((54, 96), (108, 192), (216, 384)):
+        ref = (F.interpolate(a, size=size, mode="bicubic", align_corners=False) +
+               F.interpolate(b, size=size, mode="bicubic", align_corners=False))
+        got = ops.rt_bicubic_sum(a.cuda(), b.cuda(), size, clamp=False).cpu()
+        assert (got - ref).abs().max() <= 2e-5
+        got = ops.rt_bicubic_sum(a.cuda(), b.cuda(), size, clamp=True).cpu()
+        assert (got - ref.clamp(0, 1)).abs().max() <= 2e-5
+
+
+@pytest.fixture(scope="module")
+def rt_model():
+    from transformerupscaler_amd.weights import rt_deterministic_state_dict
+    m = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
+    m.load_state_dict(rt_deterministic_state_dict(0))
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name,kw", [("rt_fwd_1080p.npz", dict(res_out=(1080, 1920))), ("rt_fwd_x2.npz", dict(upscale_factor=2))])
+def test_rt_model_matches_reference_fixture(rt_model, golden_dir, name, kw):
+    d = dict(np.load(os.path.join(golden_dir, name)))
+    x = torch.rand((1, 3, 720, 1280), generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        y = rt_model(x.cuda(), **kw).cpu()
+    worst, se, n = 0.0, 0.0, 0
+    for i, (a, b) in enumerate(zip(d["ys"].tolist(), d["xs"].tolist())):
+        diff = y[0, :, a:a + 32, b:b + 32] - torch.from_numpy(d["patches"][i])
+        worst = max(worst, diff.abs().max().item()); se += (diff.double() ** 2).sum().item(); n += diff.numel()
+    psnr = 10 * np.log10(1.0 / max(se / n, 1e-20))
+    print(name, "max abs", worst, "PSNR", psnr)
+    assert worst <= 2.5e-2 and psnr >= 50.0
+    assert abs(y.double().mean().item() - d["stats"][0]) < 2e-3
+    assert np.abs(y[0].double().mean(dim=(0, 2)).float().numpy() - d["row_means"]).max() < 5e-3
+
+
+def test_rt_rejects_other_sizes_and_training(rt_model):
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            rt_model(torch.rand(1, 3, 540, 960).cuda())
+    with pytest.raises(NotImplementedError):
+        rt_model(torch.rand(1, 3, 720, 1280).cuda())

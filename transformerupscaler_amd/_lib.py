@@ -36,6 +36,12 @@ SIGNATURES = {
     "tup_fused_mlp_fwd": [P, P, P, P, P, P, P, I, P],
     "tup_patch_embed_fwd": [P, P, P, P, I, I, I, P],
     "tup_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
+    # ResidualTransformer
+    "tup_rt_patch_embed_fwd": [P, P, P, P, P, I, I, I, P],
+    "tup_rt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
+    "tup_rt_attention_fwd": [P, P, I, I, P],
+    "tup_layernorm128_fwd": [P, P, P, P, I, P],
+    "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     # backward
     "tup_gemm_wgrad": [P, I, I, P, I, I, P, I, I, I, I, P],
     "tup_patch_wgrad": [P, P, P, I, I, I, I, P],

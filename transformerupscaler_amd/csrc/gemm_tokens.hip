@@ -31,6 +31,8 @@ struct GemmParams {
     int reflect;                 // A_PATCH: 1 = reflect-pad beyond the map, 0 = zeros
     uint32_t drop_thresh, drop_seed; float drop_inv_keep;      // E_RES_F32: dropout on (acc + bias) before "+ res"
     const float* ln_gamma; const float* ln_beta;               // panel kernel, A_LN: LayerNorm fused into the A load
+    int linear_tokens;            // patch modes: token rows are a plain [B][Ht][Wt] grid (ResidualTransformer), not windows
+    const float* pos;             // E_PATCH_EMBED with linear tokens: + pos_embed[token][n]
     int M, N, K;
     int H, W, Ht, Wt_, nWx, nWy; // geometry for the patch modes (token rows are in window layout)
 };
@@ -42,6 +44,15 @@ struct TokPos { int b, ty, tx; bool valid; };
 
 TUP_DEVICE TokPos token_of_row(int m, const GemmParams& p) {
     TokPos t;
+    if (p.linear_tokens) {
+        const int per = p.Ht * p.Wt_;
+        t.b = m / per;
+        const int tok = m - t.b * per;
+        t.ty = tok / p.Wt_;
+        t.tx = tok - t.ty * p.Wt_;
+        t.valid = true;
+        return t;
+    }
     const int tok = m & 63;
     int win = m >> 6;
     const int wx = win % p.nWx; win /= p.nWx;
@@ -107,6 +118,11 @@ TUP_DEVICE void gemm_store_row(const GemmParams& p, int m, int n0, int g, const 
             f32x4 ov;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ov[e] = t.valid ? v[4 * q + e] + bvec[4 * q + e] : 0.f;
+            if (p.pos) {       // ResidualTransformer: tokens + pos_embed (model.py:140)
+                const f32x4 pv = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(m % (p.Ht * p.Wt_)) * p.ldo + nb + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] += pv[e];
+            }
             *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
         }
     } else if constexpr (EPI == E_GELU_BWD) {
@@ -594,5 +610,32 @@ extern "C" int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_p
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = gx; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = gmap_pad; p.skip = nullptr;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
+    return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- ResidualTransformer token entry / exit (plain [B][45][80] token grid, no windows) ----
+// feat bf16 NHWC [B][H][W][64] (H, W multiples of 8); Wt bf16 [128][4096]; pos fp32 [H/8*W/8][128]; x_out fp32 [B*T][128].
+// patch_embed + flatten/transpose + pos_embed: models/ResidualTransformer/model.py:135-140.
+extern "C" int tup_rt_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, const float* pos, float* x_out,
+                                      int B, int H, int W, void* stream)
+{
+    if (H % 8 || W % 8) return (int)hipErrorInvalidValue;
+    GemmParams p{};
+    p.H = H; p.W = W; p.Ht = H / 8; p.Wt_ = W / 8; p.linear_tokens = 1; p.pos = pos; p.reflect = 0;
+    p.A = feat; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = x_out; p.ldo = 128;
+    p.M = B * p.Ht * p.Wt_; p.N = 128; p.K = 4096;
+    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// x fp32 [B*T][128]; Wt bf16 [4096][128] (n = (i*8+j)*64 + o); out = skip + ConvTranspose(k8,s8)(x) + bias, NHWC bf16.
+// transpose/view + patch_unembed + skip add: model.py:147-153.
+extern "C" int tup_rt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip, void* out,
+                                        int B, int H, int W, void* stream)
+{
+    if (H % 8 || W % 8) return (int)hipErrorInvalidValue;
+    GemmParams p{};
+    p.H = H; p.W = W; p.Ht = H / 8; p.Wt_ = W / 8; p.linear_tokens = 1;
+    p.A = x; p.lda = 128; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
+    p.M = B * p.Ht * p.Wt_; p.N = 4096; p.K = 128;
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -426,3 +426,63 @@ def feat_grad_combine(a, b, gpe, feat):
     _lib.call("tup_feat_grad_combine", _chk(a, BF16, feat.shape, "a"), _opt(b, BF16, feat.shape, "b"),
               _chk(gpe, BF16, (B, hp, wp, 64), "gpe"), _chk(feat, BF16, None, "feat"), out.data_ptr(), B, H, W, _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# ResidualTransformer wrappers
+# ------------------------------------------------------------------------------------------------
+def rt_patch_embed(feat, wt, bias, pos):
+    B, H, W, C = feat.shape
+    T = (H // 8) * (W // 8)
+    x = torch.empty((B * T, 128), dtype=F32, device=feat.device)
+    _lib.call("tup_rt_patch_embed_fwd", _chk(feat, BF16, None, "feat"), _chk(wt, BF16, (128, 4096), "wt"), _chk(bias, F32, (128,), "bias"),
+              _chk(pos, F32, (T, 128), "pos"), x.data_ptr(), B, H, W, _stream())
+    return x
+
+
+def rt_patch_unembed(x, wt, bias, skip):
+    B, H, W, C = skip.shape
+    out = torch.empty_like(skip)
+    _lib.call("tup_rt_patch_unembed_fwd", _chk(x, F32, (B * (H // 8) * (W // 8), 128), "x"), _chk(wt, BF16, (4096, 128), "wt"),
+              _chk(bias, F32, (64,), "bias"), _chk(skip, BF16, None, "skip"), out.data_ptr(), B, H, W, _stream())
+    return out
+
+
+def rt_attention(qkv, B, N):
+    out = torch.empty((B * N, 128), dtype=BF16, device=qkv.device)
+    _lib.call("tup_rt_attention_fwd", _chk(qkv, BF16, (B * N, 384), "qkv"), out.data_ptr(), B, N, _stream())
+    return out
+
+
+def layernorm128(x, gamma, beta):
+    M = x.shape[0]
+    y = torch.empty((M, 128), dtype=BF16, device=x.device)
+    _lib.call("tup_layernorm128_fwd", _chk(x, F32, (M, 128), "x"), _chk(gamma, F32, (128,), "gamma"), _chk(beta, F32, (128,), "beta"),
+              y.data_ptr(), M, _stream())
+    return y
+
+
+_BIC_CACHE = {}
+
+
+def _bicubic_on(device, in_size, out_size):
+    key = (str(device), in_size, out_size)
+    if key not in _BIC_CACHE:
+        from .resize_taps import bicubic_taps
+        idx, w = bicubic_taps(in_size, out_size)
+        _BIC_CACHE[key] = (torch.from_numpy(idx).to(device), torch.from_numpy(w).to(device))
+    return _BIC_CACHE[key]
+
+
+def rt_bicubic_sum(a, b, size, clamp=True):
+    """clamp(bicubic(a -> size) + bicubic(b -> size)) for planar fp32 [B][3][H][W] tensors."""
+    B, C, Ha, Wa = a.shape
+    _, _, Hb, Wb = b.shape
+    Ho, Wo = size
+    ayi, ayw = _bicubic_on(a.device, Ha, Ho); axi, axw = _bicubic_on(a.device, Wa, Wo)
+    byi, byw = _bicubic_on(a.device, Hb, Ho); bxi, bxw = _bicubic_on(a.device, Wb, Wo)
+    out = torch.empty((B, C, Ho, Wo), dtype=F32, device=a.device)
+    _lib.call("tup_rt_bicubic_sum_fwd", _chk(a, F32, None, "a"), _chk(b, F32, (B, C, Hb, Wb), "b"), out.data_ptr(),
+              ayi.data_ptr(), ayw.data_ptr(), axi.data_ptr(), axw.data_ptr(), byi.data_ptr(), byw.data_ptr(),
+              bxi.data_ptr(), bxw.data_ptr(), B * C, Ha, Wa, Hb, Wb, Ho, Wo, int(clamp), _stream())
+    return out

@@ -194,3 +194,50 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
             pk[f"b{i}.{nm}.wd"] = pack_linear(t(f"{p}.{key}.weight").t().contiguous())
     return pk
+
+
+# ------------------------------------------------------------------------------------------------
+# ResidualTransformer
+# ------------------------------------------------------------------------------------------------
+def pack_conv_c64_stride2(weight: torch.Tensor, bias):
+    """Conv2d(64, 64, 3, stride=2, padding=1) as a 3x3 conv over the space-to-depth (2x2 -> 256 channel) input that
+    tup_conv3x3_c64_fwd reads with in_r = 2: chunk (si, sj), block tap (dy, dx) <-> original tap
+    (ky, kx) = (2(dy-1)+si+1, 2(dx-1)+sj+1) when that lies in 0..2, zero otherwise.  bf16 [1][4][9][64][64]."""
+    assert tuple(weight.shape) == (64, 64, 3, 3)
+    w = torch.zeros(4, 9, 64, 64, dtype=weight.dtype, device=weight.device)          # [chunk][tap][cout][cin]
+    for si in range(2):
+        for sj in range(2):
+            for dy in range(3):
+                for dx in range(3):
+                    ky, kx = 2 * (dy - 1) + si + 1, 2 * (dx - 1) + sj + 1
+                    if 0 <= ky <= 2 and 0 <= kx <= 2:
+                        w[si * 2 + sj, dy * 3 + dx] = weight[:, :, ky, kx]
+    w = w.index_select(2, _PERM64.to(w.device))
+    b = None if bias is None else bias.reshape(1, 64).contiguous().float()
+    return w.unsqueeze(0).contiguous().to(torch.bfloat16), b
+
+
+def pack_rt_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    pk: Dict[str, torch.Tensor] = {}
+    f32 = lambda t: t.detach().float().contiguous()
+    t = lambda k: sd[k].detach()
+    pk["conv1.w"] = pack_conv1(t("conv1.weight")); pk["conv1.b"] = f32(sd["conv1.bias"])
+    pk["conv2.w"], pk["conv2.b"] = pack_conv_c64(t("conv2.weight"), t("conv2.bias"), 1)
+    pk["ds.w"], pk["ds.b"] = pack_conv_c64_stride2(t("downsample.weight"), t("downsample.bias"))
+    pk["pe.w"] = pack_linear(t("patch_embed.weight").permute(0, 2, 3, 1).reshape(128, 4096)); pk["pe.b"] = f32(sd["patch_embed.bias"])
+    pk["pos"] = f32(sd["pos_embed"]).reshape(-1, 128).contiguous()
+    nb = 0
+    while f"transformer_blocks.{nb}.norm1.weight" in sd:
+        p = f"transformer_blocks.{nb}"
+        for nm in ("norm1", "norm2"):
+            pk[f"b{nb}.{nm}.w"] = f32(sd[f"{p}.{nm}.weight"]); pk[f"b{nb}.{nm}.b"] = f32(sd[f"{p}.{nm}.bias"])
+        pk[f"b{nb}.in.w"] = pack_linear(t(f"{p}.attn.in_proj_weight")); pk[f"b{nb}.in.b"] = f32(sd[f"{p}.attn.in_proj_bias"])
+        pk[f"b{nb}.out.w"] = pack_linear(t(f"{p}.attn.out_proj.weight")); pk[f"b{nb}.out.b"] = f32(sd[f"{p}.attn.out_proj.bias"])
+        pk[f"b{nb}.fc1.w"] = pack_linear(t(f"{p}.mlp.0.weight")); pk[f"b{nb}.fc1.b"] = f32(sd[f"{p}.mlp.0.bias"])
+        pk[f"b{nb}.fc2.w"] = pack_linear(t(f"{p}.mlp.2.weight")); pk[f"b{nb}.fc2.b"] = f32(sd[f"{p}.mlp.2.bias"])
+        nb += 1
+    pk["nblocks"] = nb
+    pk["pu.w"] = pack_linear(t("patch_unembed.weight").permute(2, 3, 1, 0).reshape(4096, 128)); pk["pu.b"] = f32(sd["patch_unembed.bias"])
+    pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(t("decoder_conv1.weight"), t("decoder_conv1.bias"), 1)
+    pk["dec2.w"] = pack_conv_c64_thin(t("decoder_conv2.weight")); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])
+    return pk

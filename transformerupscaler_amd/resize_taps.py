@@ -73,3 +73,22 @@ def tile_extent(in_size: int, out_size: int, tile: int) -> int:
         o1 = min(o0 + tile, out_size) - 1
         best = max(best, int(lo[o1] + n[o1] - lo[o0]))
     return best
+
+
+@functools.lru_cache(maxsize=64)
+def bicubic_taps(in_size: int, out_size: int):
+    """F.interpolate(mode='bicubic', align_corners=False) (aten upsample_bicubic2d, A = -0.75): per output index
+    four clamped source indices and float32 weights.  Third-party PyTorch semantics (reference
+    models/ResidualTransformer/model.py:125,160 call it); vectorised numpy."""
+    f = np.float32
+    scale = f(in_size) / f(out_size)
+    o = np.arange(out_size, dtype=np.float32)
+    src = (scale * (o + f(0.5)) - f(0.5)).astype(np.float32)
+    fl = np.floor(src)
+    t = (src - fl).astype(np.float32)
+    A = f(-0.75)
+    c1 = lambda x: (((A + f(2)) * x - (A + f(3))) * x * x + f(1)).astype(np.float32)
+    c2 = lambda x: (((A * x - f(5) * A) * x + f(8) * A) * x - f(4) * A).astype(np.float32)
+    w = np.stack([c2(t + f(1)), c1(t), c1(f(1) - t), c2(f(2) - t)], axis=1).astype(np.float32)
+    idx = np.clip(fl.astype(np.int64)[:, None] - 1 + np.arange(4)[None, :], 0, in_size - 1).astype(np.int32)
+    return np.ascontiguousarray(idx), np.ascontiguousarray(w)

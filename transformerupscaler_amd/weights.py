@@ -106,3 +106,54 @@ def deterministic_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str, to
                 t = t * 3.0     # widen the output spread so both clamp edges are exercised
         sd[name] = t.to(dtype)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# ResidualTransformer (reference models/ResidualTransformer/model.py:53-112; BASELINE.json config 5)
+# ------------------------------------------------------------------------------------------------
+RT_DIM, RT_BLOCKS, RT_HEADS, RT_MLP, RT_TOKENS_H, RT_TOKENS_W = 128, 8, 8, 512, 45, 80
+
+
+def rt_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["pos_embed"] = (1, RT_TOKENS_H * RT_TOKENS_W, RT_DIM)
+    s["conv1.weight"] = (BASE, IN_CH, 3, 3); s["conv1.bias"] = (BASE,)
+    s["conv2.weight"] = (BASE, BASE, 3, 3); s["conv2.bias"] = (BASE,)
+    s["downsample.weight"] = (BASE, BASE, 3, 3); s["downsample.bias"] = (BASE,)
+    s["patch_embed.weight"] = (RT_DIM, BASE, 8, 8); s["patch_embed.bias"] = (RT_DIM,)
+    for i in range(RT_BLOCKS):
+        p = f"transformer_blocks.{i}"
+        s[p + ".norm1.weight"] = (RT_DIM,); s[p + ".norm1.bias"] = (RT_DIM,)
+        s[p + ".attn.in_proj_weight"] = (3 * RT_DIM, RT_DIM); s[p + ".attn.in_proj_bias"] = (3 * RT_DIM,)
+        s[p + ".attn.out_proj.weight"] = (RT_DIM, RT_DIM); s[p + ".attn.out_proj.bias"] = (RT_DIM,)
+        s[p + ".norm2.weight"] = (RT_DIM,); s[p + ".norm2.bias"] = (RT_DIM,)
+        s[p + ".mlp.0.weight"] = (RT_MLP, RT_DIM); s[p + ".mlp.0.bias"] = (RT_MLP,)
+        s[p + ".mlp.2.weight"] = (RT_DIM, RT_MLP); s[p + ".mlp.2.bias"] = (RT_DIM,)
+    s["patch_unembed.weight"] = (RT_DIM, BASE, 8, 8); s["patch_unembed.bias"] = (BASE,)
+    s["decoder_conv1.weight"] = (BASE, BASE, 3, 3); s["decoder_conv1.bias"] = (BASE,)
+    s["decoder_conv2.weight"] = (IN_CH, BASE, 3, 3); s["decoder_conv2.bias"] = (IN_CH,)
+    return s
+
+
+def rt_deterministic_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Same recipe as deterministic_state_dict for the ResidualTransformer keys (pos_embed ~ N(0, 0.5))."""
+    sd: Dict[str, torch.Tensor] = OrderedDict()
+    shapes = rt_param_shapes()
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(("rt." + name).encode()) + 7919 * seed) & 0x7FFFFFFF)
+        if name == "pos_embed":
+            t = torch.randn(shape, generator=g) * 0.5
+        elif ".norm" in name and name.endswith("weight"):
+            t = 1.0 + (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif ".norm" in name:
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif name.endswith("bias"):
+            wname = name[:-4] + "weight"
+            fan = _fan_in(wname, shapes[wname]) if wname in shapes else RT_DIM
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan)
+            if name == "decoder_conv2.bias":
+                t = t * 0.1
+        else:
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(_fan_in(name, shape))
+        sd[name] = t.to(dtype)
+    return sd

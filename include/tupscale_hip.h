@@ -147,8 +147,13 @@ int tup_rt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, 
                              int B, int H, int W, void* stream);
 
 /* nn.MultiheadAttention(128, 8 heads) core, eval mode (model.py:31,43): qkv bf16 [B][N][384] -> out bf16 [B][N][128];
- * flash-style (online softmax), any N. */
-int tup_rt_attention_fwd(const void* qkv, void* out, int B, int N, void* stream);
+ * flash-style (online softmax), any N; lse (optional) receives the per-query log-sum-exp for the backward. */
+int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, void* stream);
+
+/* Its backward (P recomputed from the saved log-sum-exp `lse` fp32 [B][8][N]; two passes, no atomics):
+ * out/gout bf16 [B][N][128], work fp32 [B][8][N] scratch, gqkv bf16 [B][N][384]. */
+int tup_rt_attention_bwd(const void* qkv, const void* out, const void* gout, const float* lse, float* work,
+                         void* gqkv, int B, int N, void* stream);
 
 /* nn.LayerNorm(128) (model.py:30,32): x fp32 [M][128] -> y bf16. */
 int tup_layernorm128_fwd(const float* x, const float* gamma, const float* beta, void* y, int M, void* stream);

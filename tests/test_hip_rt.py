@@ -89,3 +89,19 @@ def test_rt_rejects_other_sizes_and_training(rt_model):
             rt_model(torch.rand(1, 3, 540, 960).cuda())
     with pytest.raises(NotImplementedError):
         rt_model(torch.rand(1, 3, 720, 1280).cuda())
+
+
+@pytest.mark.parametrize("B,N", [(1, 3600), (2, 200)])
+def test_rt_attention_backward(B, N):
+    from transformerupscaler_amd import ops
+    qkv = bf(rnd((B, N, 384), 14, 1.5)).requires_grad_(True)
+    q, k, v = qkv.view(B, N, 3, 8, 16).permute(2, 0, 3, 1, 4)
+    out = (torch.softmax((q * 0.25) @ k.transpose(-2, -1), -1) @ v).transpose(1, 2).reshape(B * N, 128)
+    gout = bf(rnd((B * N, 128), 15))
+    out.backward(gout)
+    qd = qkv.detach().view(B * N, 384).to(torch.bfloat16).cuda()
+    o, lse = ops.rt_attention(qd, B, N, save_lse=True)
+    gq = ops.rt_attention_bwd(qd, o, gout.to(torch.bfloat16).cuda(), lse, B, N).float().cpu()
+    ref = qkv.grad.view(B * N, 384)
+    err = (gq - ref).abs().max().item()
+    assert err <= 2e-2 + 2e-2 * ref.abs().max().item(), err

@@ -39,7 +39,8 @@ SIGNATURES = {
     # ResidualTransformer
     "tup_rt_patch_embed_fwd": [P, P, P, P, P, I, I, I, P],
     "tup_rt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
-    "tup_rt_attention_fwd": [P, P, I, I, P],
+    "tup_rt_attention_fwd": [P, P, P, I, I, P],
+    "tup_rt_attention_bwd": [P, P, P, P, P, P, I, I, P],
     "tup_layernorm128_fwd": [P, P, P, P, I, P],
     "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     # backward

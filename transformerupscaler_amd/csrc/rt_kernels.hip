@@ -13,7 +13,7 @@ constexpr int RD = 128, RH = 8, HD = 16;
 
 // ---- flash-style attention, one wave per (batch, head, 64-query tile); S^T tiles in registers, online softmax ----
 __global__ __launch_bounds__(256) void rt_attention_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int N, int qtiles)
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int B, int N, int qtiles)
 {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[4][64 * HD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
         const int q = q0 + 16 * qt + p;
         if (q >= N) continue;
         const float inv = 1.0f / lrun[qt];
+        if (lse && g == 0) lse[((size_t)b * RH + h) * N + q] = mrun[qt] + __logf(lrun[qt]);     // saved for the backward
         bf16_t* op = out + ((size_t)b * N + q) * RD + h * HD + 4 * g;
         *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(oacc[qt][0] * inv, oacc[qt][1] * inv), pack_bf16x2(oacc[qt][2] * inv, oacc[qt][3] * inv)};
     }
@@ -188,16 +189,227 @@ __global__ __launch_bounds__(256) void rt_bicubic_sum_kernel(
     out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention backward (flash-style, P recomputed from q, k and the saved log-sum-exp), two passes so that no
+// gradient needs cross-workgroup accumulation:
+//   pass A, one wave per (b, h, 64-query tile), loops over key tiles:   dQ
+//   pass B, one wave per (b, h, 64-key tile),   loops over query tiles: dK, dV
+// Same register-orientation trick as the window kernel (attention_bwd.hip): the products whose contraction runs
+// over keys use the T-layout tiles (rows = key), those over queries the N-layout tiles (rows = query), so every
+// B operand is an accumulator tile converted in place.  D[q] = sum_d dO[q][d] O[q][d] comes from a tiny pre-pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rt_attn_bwd_prep_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ go,
+                                                               float* __restrict__ dsum, int B, int N)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;          // over B*N*8
+    if (idx >= (long long)B * N * RH) return;
+    const int h = (int)(idx % RH);
+    const long long row = idx / RH;                                            // b*N + q
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(o + row * RD + h * HD), a1 = *reinterpret_cast<const u32x4*>(o + row * RD + h * HD + 8);
+    const u32x4 b0 = *reinterpret_cast<const u32x4*>(go + row * RD + h * HD), b1 = *reinterpret_cast<const u32x4*>(go + row * RD + h * HD + 8);
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        s += __builtin_bit_cast(float, a0[q] << 16) * __builtin_bit_cast(float, b0[q] << 16) +
+             __builtin_bit_cast(float, a0[q] & 0xffff0000u) * __builtin_bit_cast(float, b0[q] & 0xffff0000u) +
+             __builtin_bit_cast(float, a1[q] << 16) * __builtin_bit_cast(float, b1[q] << 16) +
+             __builtin_bit_cast(float, a1[q] & 0xffff0000u) * __builtin_bit_cast(float, b1[q] & 0xffff0000u);
+    }
+    const int b = (int)(row / N), qi = (int)(row % N);
+    dsum[((size_t)b * RH + h) * N + qi] = s;
+}
+
+TUP_DEVICE s16x4 f4_to_bf16x4(const f32x4 v) {
+    const u32x2 p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    return __builtin_bit_cast(s16x4, p);
+}
+TUP_DEVICE void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ go, const float* __restrict__ lse,
+    const float* __restrict__ dsum, bf16_t* __restrict__ gqkv, int B, int N, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t klds[4][64 * HD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    int wid = blockIdx.x * 4 + wave;
+    const int total = B * RH * tiles;
+    const bool active = wid < total;
+    if (!active) wid = total - 1;
+    const int qt0 = wid % tiles, h = (wid / tiles) % RH, b = wid / (tiles * RH);
+    const bf16_t* base = qkv + (size_t)b * N * (3 * RD) + h * HD;
+    const bf16_t* gbase = go + (size_t)b * N * RD + h * HD;
+    const int q0 = qt0 * 64;
+    s16x4 qf[4], dof[4];
+    float lc[4], dc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int q = min(q0 + 16 * t + p, N - 1);
+        qf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)q * (3 * RD) + 4 * g);
+        dof[t] = *reinterpret_cast<const s16x4*>(gbase + (size_t)q * RD + 4 * g);
+        lc[t] = lse[((size_t)b * RH + h) * N + q];
+        dc[t] = dsum[((size_t)b * RH + h) * N + q];
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt0 = 0; kt0 < tiles; ++kt0) {
+        const int k0 = kt0 * 64;
+        {
+            const int row = min(k0 + lane, N - 1);
+            const bf16_t* kr = base + (size_t)row * (3 * RD) + RD;
+            *reinterpret_cast<u32x4*>(&klds[wave][lane * HD]) = *reinterpret_cast<const u32x4*>(kr);
+            *reinterpret_cast<u32x4*>(&klds[wave][lane * HD + 8]) = *reinterpret_cast<const u32x4*>(kr + 8);
+        }
+        s16x4 kf[4], vf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = min(k0 + 16 * t + p, N - 1);
+            kf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)row * (3 * RD) + RD + 4 * g);
+            vf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)row * (3 * RD) + 2 * RD + 4 * g);
+        }
+        wave_sync_lds();
+        s16x4 kT[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            bf16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = klds[wave][(16 * kt + 4 * g + j) * HD + p];
+            kT[kt] = __builtin_bit_cast(s16x4, t);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                const f32x4 dp = mfma16x16x16(vf[kt], dof[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                f32x4 ds;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + 16 * kt + 4 * g + e;
+                    const float pr = key < N ? __expf(s[e] * 0.25f - lc[qt]) : 0.f;
+                    ds[e] = pr * (dp[e] - dc[qt]);
+                }
+                dq[qt] = mfma16x16x16(kT[kt], f4_to_bf16x4(ds), dq[qt]);
+            }
+        wave_sync_lds();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = q0 + 16 * qt + p;
+        if (q >= N) continue;
+        bf16_t* op = gqkv + ((size_t)b * N + q) * (3 * RD) + h * HD + 4 * g;
+        *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(dq[qt][0] * 0.25f, dq[qt][1] * 0.25f), pack_bf16x2(dq[qt][2] * 0.25f, dq[qt][3] * 0.25f)};
+    }
+}
+
+__global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ go, const float* __restrict__ lse,
+    const float* __restrict__ dsum, bf16_t* __restrict__ gqkv, int B, int N, int tiles)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4][2][64 * HD];          // per wave: Q tile, dO tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    int wid = blockIdx.x * 4 + wave;
+    const int total = B * RH * tiles;
+    const bool active = wid < total;
+    if (!active) wid = total - 1;
+    const int kt0 = wid % tiles, h = (wid / tiles) % RH, b = wid / (tiles * RH);
+    const bf16_t* base = qkv + (size_t)b * N * (3 * RD) + h * HD;
+    const bf16_t* gbase = go + (size_t)b * N * RD + h * HD;
+    const float* lrow = lse + ((size_t)b * RH + h) * N;
+    const float* drow = dsum + ((size_t)b * RH + h) * N;
+    const int k0 = kt0 * 64;
+    s16x4 kf[4], vf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = min(k0 + 16 * t + p, N - 1);
+        kf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)row * (3 * RD) + RD + 4 * g);
+        vf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)row * (3 * RD) + 2 * RD + 4 * g);
+    }
+    f32x4 dvT[4], dkT[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dvT[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dkT[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    bf16_t* ql = lds[wave][0];
+    bf16_t* dol = lds[wave][1];
+    for (int qt0 = 0; qt0 < tiles; ++qt0) {
+        const int q0 = qt0 * 64;
+        {
+            const int row = min(q0 + lane, N - 1);
+            const bf16_t* qr = base + (size_t)row * (3 * RD);
+            const bf16_t* gr = gbase + (size_t)row * RD;
+            *reinterpret_cast<u32x4*>(ql + lane * HD) = *reinterpret_cast<const u32x4*>(qr);
+            *reinterpret_cast<u32x4*>(ql + lane * HD + 8) = *reinterpret_cast<const u32x4*>(qr + 8);
+            *reinterpret_cast<u32x4*>(dol + lane * HD) = *reinterpret_cast<const u32x4*>(gr);
+            *reinterpret_cast<u32x4*>(dol + lane * HD + 8) = *reinterpret_cast<const u32x4*>(gr + 8);
+        }
+        s16x4 qf[4], dof[4];
+        f32x4 lr[4], dr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int q = min(q0 + 16 * t + p, N - 1);
+            qf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)q * (3 * RD) + 4 * g);
+            dof[t] = *reinterpret_cast<const s16x4*>(gbase + (size_t)q * RD + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qq = q0 + 16 * t + 4 * g + e;
+                lr[t][e] = qq < N ? lrow[qq] : 0.f;
+                dr[t][e] = qq < N ? drow[qq] : 0.f;
+            }
+        }
+        wave_sync_lds();
+        s16x4 qT[4], doT[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bf16x4 a, c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a[j] = ql[(16 * t + 4 * g + j) * HD + p]; c[j] = dol[(16 * t + 4 * g + j) * HD + p]; }
+            qT[t] = __builtin_bit_cast(s16x4, a); doT[t] = __builtin_bit_cast(s16x4, c);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});       // rows query 4g+e, cols key p
+                const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+                f32x4 pr, ds;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = q0 + 16 * qt + 4 * g + e;
+                    pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
+                    ds[e] = pr[e] * (dp[e] - dr[qt][e]);
+                }
+                dvT[kt] = mfma16x16x16(doT[qt], f4_to_bf16x4(pr), dvT[kt]);
+                dkT[kt] = mfma16x16x16(qT[qt], f4_to_bf16x4(ds), dkT[kt]);
+            }
+        wave_sync_lds();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int key = k0 + 16 * kt + p;
+        if (key >= N) continue;
+        bf16_t* op = gqkv + ((size_t)b * N + key) * (3 * RD) + h * HD + 4 * g;
+        *reinterpret_cast<u32x2*>(op + RD) = u32x2{pack_bf16x2(dkT[kt][0] * 0.25f, dkT[kt][1] * 0.25f), pack_bf16x2(dkT[kt][2] * 0.25f, dkT[kt][3] * 0.25f)};
+        *reinterpret_cast<u32x2*>(op + 2 * RD) = u32x2{pack_bf16x2(dvT[kt][0], dvT[kt][1]), pack_bf16x2(dvT[kt][2], dvT[kt][3])};
+    }
+}
+
 }  // namespace
 
-// qkv bf16 [B][N][384] (q | k | v, each 8 heads x 16); out bf16 [B][N][128].  Eval-mode attention (no dropout).
-extern "C" int tup_rt_attention_fwd(const void* qkv, void* out, int B, int N, void* stream)
+// qkv bf16 [B][N][384] (q | k | v, each 8 heads x 16); out bf16 [B][N][128]; lse fp32 [B][8][N] (optional: log-sum-exp
+// of the scaled scores per query, saved for the backward).  Eval-mode attention (no dropout).
+extern "C" int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, void* stream)
 {
     if (B <= 0 || N <= 0) return 0;
     const int qtiles = (N + 63) / 64;
     const long long waves = (long long)B * RH * qtiles;
     rt_attention_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, (bf16_t*)out, B, N, qtiles);
+        (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, qtiles);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -222,6 +434,26 @@ extern "C" int tup_rt_bicubic_sum_fwd(const float* a, const float* b, float* out
     dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, planes);
     rt_bicubic_sum_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         a, b, out, ayi, ayw, axi, axw, byi, byw, bxi, bxw, Ha, Wa, Hb, Wb, Ho, Wo, clamp01);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward of tup_rt_attention_fwd: qkv bf16 [B][N][384], out (forward output) and gout bf16 [B][N][128], lse fp32
+// [B][8][N]; work fp32 [B][8][N] scratch; gqkv bf16 [B][N][384] (overwritten).
+extern "C" int tup_rt_attention_bwd(const void* qkv, const void* out, const void* gout, const float* lse, float* work,
+                                    void* gqkv, int B, int N, void* stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long nprep = (long long)B * N * RH;
+    rt_attn_bwd_prep_kernel<<<dim3((unsigned)((nprep + 255) / 256)), dim3(256), 0, s>>>((const bf16_t*)out, (const bf16_t*)gout, work, B, N);
+    TUP_CHECK_LAUNCH();
+    const int tiles = (N + 63) / 64;
+    const long long waves = (long long)B * RH * tiles;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    rt_attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles);
+    TUP_CHECK_LAUNCH();
+    rt_attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles);
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -448,10 +448,20 @@ def rt_patch_unembed(x, wt, bias, skip):
     return out
 
 
-def rt_attention(qkv, B, N):
+def rt_attention(qkv, B, N, save_lse=False):
     out = torch.empty((B * N, 128), dtype=BF16, device=qkv.device)
-    _lib.call("tup_rt_attention_fwd", _chk(qkv, BF16, (B * N, 384), "qkv"), out.data_ptr(), B, N, _stream())
-    return out
+    lse = torch.empty((B, 8, N), dtype=F32, device=qkv.device) if save_lse else None
+    _lib.call("tup_rt_attention_fwd", _chk(qkv, BF16, (B * N, 384), "qkv"), out.data_ptr(),
+              None if lse is None else lse.data_ptr(), B, N, _stream())
+    return (out, lse) if save_lse else out
+
+
+def rt_attention_bwd(qkv, out, gout, lse, B, N):
+    gqkv = torch.empty((B * N, 384), dtype=BF16, device=qkv.device)
+    work = torch.empty((B, 8, N), dtype=F32, device=qkv.device)
+    _lib.call("tup_rt_attention_bwd", _chk(qkv, BF16, (B * N, 384), "qkv"), _chk(out, BF16, (B * N, 128), "out"),
+              _chk(gout, BF16, (B * N, 128), "gout"), _chk(lse, F32, (B, 8, N), "lse"), work.data_ptr(), gqkv.data_ptr(), B, N, _stream())
+    return gqkv
 
 
 def layernorm128(x, gamma, beta):

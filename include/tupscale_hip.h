@@ -147,16 +147,19 @@ int tup_rt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, 
                              int B, int H, int W, void* stream);
 
 /* nn.MultiheadAttention(128, 8 heads) core, eval mode (model.py:31,43): qkv bf16 [B][N][384] -> out bf16 [B][N][128];
- * flash-style (online softmax), any N; lse (optional) receives the per-query log-sum-exp for the backward. */
-int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, void* stream);
+ * flash-style (online softmax), any N; lse (optional) receives the per-query log-sum-exp for the backward.
+ * drop_p > 0: nn.MultiheadAttention's dropout on the attention probabilities, stateless hash mask on (image, head, q, k). */
+int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, float drop_p, unsigned int drop_seed,
+                         void* stream);
 
 /* Its backward (P recomputed from the saved log-sum-exp `lse` fp32 [B][8][N]; two passes, no atomics):
  * out/gout bf16 [B][N][128], work fp32 [B][8][N] scratch, gqkv bf16 [B][N][384]. */
 int tup_rt_attention_bwd(const void* qkv, const void* out, const void* gout, const float* lse, float* work,
-                         void* gqkv, int B, int N, void* stream);
+                         void* gqkv, int B, int N, float drop_p, unsigned int drop_seed, void* stream);
 
 /* nn.LayerNorm(128) (model.py:30,32): x fp32 [M][128] -> y bf16. */
-int tup_layernorm128_fwd(const float* x, const float* gamma, const float* beta, void* y, int M, void* stream);
+int tup_layernorm128_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int M, void* stream);
 
 /* out = clamp(F.interpolate(a, bicubic) + F.interpolate(b, bicubic)) (model.py:125,160-164); tables [Ho][4]/[Wo][4]
  * of clamped source indices and weights per source (align_corners=False, A=-0.75). */
@@ -235,6 +238,28 @@ int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, flo
  * out = (a + b + fold_reflect(gpe)) * (feat > 0), NHWC bf16; gpe = padded map from tup_patch_embed_bwd. */
 int tup_feat_grad_combine(const void* a, const void* b, const void* gpe, const void* feat, void* out,
                           int B, int H, int W, void* stream);
+
+/* ---- ResidualTransformer backward (autograd through models/ResidualTransformer/model.py:121-165 in train.py:138) ---- */
+
+/* LayerNorm(128) backward; same contract as tup_layernorm_bwd (dgamma / dbeta fp32 [128] accumulated). */
+int tup_layernorm128_bwd(const void* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* gres, float* dx, float* dgamma, float* dbeta, int M, void* stream);
+
+/* patch_embed / patch_unembed weight gradients on the plain token grid: out fp32 [128][4096] += P^T patches(map);
+ * P fp32 [B*T][128], map NHWC bf16 [B][H][W][64], column (i*8+j)*64 + c. */
+int tup_rt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, void* stream);
+
+/* Weight gradient of the stride-2 `downsample` conv (model.py:132) as a conv over the space-to-depth input:
+ * x NHWC bf16 [B][H*xr][W*xr][64] plane xsp, gmap NHWC bf16 [B][H][W][64]; dwp fp32 [64][9][64] +=, dbias [64] += or NULL. */
+int tup_conv3x3_c64_wgrad_s2d(const void* x, const void* gmap, float* dwp, float* dbias, int B, int H, int W,
+                              int xr, int xsp, void* stream);
+
+/* Backward of tup_rt_bicubic_sum_fwd w.r.t. source a (F.interpolate bicubic + clamp, model.py:160-164): gout / out fp32
+ * [planes][Ho][Wo] (out = saved forward output, gate 0 < out < 1; NULL = no clamp), ga fp32 [planes][Ha][Wa], tmp fp32
+ * [planes][Ha][Wo]; (ystart [Ha+1], yo, yw) / (xstart [Wa+1], xo, xw) = transposed tap lists. */
+int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga, float* tmp, const int* ystart, const int* yo,
+                       const float* yw, const int* xstart, const int* xo, const float* xw, int planes, int Ha, int Wa,
+                       int Ho, int Wo, void* stream);
 
 #ifdef __cplusplus
 }

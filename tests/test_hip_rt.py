@@ -83,12 +83,10 @@ def test_rt_model_matches_reference_fixture(rt_model, golden_dir, name, kw):
     assert np.abs(y[0].double().mean(dim=(0, 2)).float().numpy() - d["row_means"]).max() < 5e-3
 
 
-def test_rt_rejects_other_sizes_and_training(rt_model):
-    with pytest.raises(RuntimeError):
+def test_rt_rejects_other_sizes(rt_model):
+    with pytest.raises(RuntimeError):                    # pos_embed fixes 3600 tokens, as in the reference (model.py:140)
         with torch.no_grad():
             rt_model(torch.rand(1, 3, 540, 960).cuda())
-    with pytest.raises(NotImplementedError):
-        rt_model(torch.rand(1, 3, 720, 1280).cuda())
 
 
 @pytest.mark.parametrize("B,N", [(1, 3600), (2, 200)])

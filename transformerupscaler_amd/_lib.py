@@ -39,9 +39,13 @@ SIGNATURES = {
     # ResidualTransformer
     "tup_rt_patch_embed_fwd": [P, P, P, P, P, I, I, I, P],
     "tup_rt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
-    "tup_rt_attention_fwd": [P, P, P, I, I, P],
-    "tup_rt_attention_bwd": [P, P, P, P, P, P, I, I, P],
-    "tup_layernorm128_fwd": [P, P, P, P, I, P],
+    "tup_rt_attention_fwd": [P, P, P, I, I, F, U, P],
+    "tup_rt_attention_bwd": [P, P, P, P, P, P, I, I, F, U, P],
+    "tup_layernorm128_fwd": [P, P, P, P, P, P, I, P],
+    "tup_layernorm128_bwd": [P, P, P, P, P, P, P, P, P, I, P],
+    "tup_rt_patch_wgrad": [P, P, P, I, I, I, P],
+    "tup_conv3x3_c64_wgrad_s2d": [P, P, P, P, I, I, I, I, I, P],
+    "tup_rt_bicubic_bwd": [P] * 10 + [I, I, I, I, I, P],
     "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     # backward
     "tup_gemm_wgrad": [P, I, I, P, I, I, P, I, I, I, I, P],

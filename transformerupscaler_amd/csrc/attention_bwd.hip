@@ -17,30 +17,32 @@ namespace {
 
 constexpr int DIM = 192, HEADS = 12, HD = 16, NTOK = 64;
 
+template <int NQ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16_t* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ gres,
     float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M)
 {
+    constexpr int LD = NQ * 64;              // 192 (FastTransformer) or 128 (ResidualTransformer)
     const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    f32x4 gm[3];
+    f32x4 gm[NQ];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) gm[q] = *reinterpret_cast<const f32x4*>(gamma + q * 64 + sub * 4);
-    float dg[12], db[12];
+    for (int q = 0; q < NQ; ++q) gm[q] = *reinterpret_cast<const f32x4*>(gamma + q * 64 + sub * 4);
+    float dg[NQ * 4], db[NQ * 4];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int i = 0; i < NQ * 4; ++i) { dg[i] = 0.f; db[i] = 0.f; }
 
     for (int row0 = blockIdx.x * 16; row0 < M; row0 += gridDim.x * 16) {
         const int row = row0 + slot;
         const bool ok = row < M;
         const int r = ok ? row : 0;
         const float mu = mean[r], rs = rstd[r];
-        float xh[12], gg[12], s1 = 0.f, s2 = 0.f;
+        float xh[NQ * 4], gg[NQ * 4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int c = q * 64 + sub * 4;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * DIM + c);
-            const u32x2 gv = *reinterpret_cast<const u32x2*>(gy + (size_t)r * DIM + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * LD + c);
+            const u32x2 gv = *reinterpret_cast<const u32x2*>(gy + (size_t)r * LD + c);
             const float gyv[4] = {__builtin_bit_cast(float, gv[0] << 16), __builtin_bit_cast(float, gv[0] & 0xffff0000u),
                                   __builtin_bit_cast(float, gv[1] << 16), __builtin_bit_cast(float, gv[1] & 0xffff0000u)};
 #pragma unroll
@@ -55,34 +57,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        s1 *= (1.0f / DIM); s2 *= (1.0f / DIM);
+        s1 *= (1.0f / LD); s2 *= (1.0f / LD);
         if (ok) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int c = q * 64 + sub * 4;
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gg[q * 4 + e] - s1 - xh[q * 4 + e] * s2);
                 if (gres) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(gres + (size_t)row * DIM + c);
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(gres + (size_t)row * LD + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += rv[e];
                 }
-                *reinterpret_cast<f32x4*>(dx + (size_t)row * DIM + c) = o;
+                *reinterpret_cast<f32x4*>(dx + (size_t)row * LD + c) = o;
             }
         }
     }
     // reduce the 16 row slots of the block, then one atomic per column
-    __shared__ float red[2][16][DIM];
+    __shared__ float red[2][16][LD];
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             red[0][slot][q * 64 + sub * 4 + e] = dg[q * 4 + e];
             red[1][slot][q * 64 + sub * 4 + e] = db[q * 4 + e];
         }
     __syncthreads();
-    if (threadIdx.x < DIM) {
+    if (threadIdx.x < LD) {
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) { a += red[0][s][threadIdx.x]; b += red[1][s][threadIdx.x]; }
@@ -336,7 +338,21 @@ extern "C" int tup_layernorm_bwd(const void* gy, const float* x, const float* me
     if (M <= 0) return 0;
     int blocks = (M + 15) / 16;
     if (blocks > 1024) blocks = 1024;
-    layernorm_bwd_kernel<<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    layernorm_bwd_kernel<3><<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Same for the 128-wide rows of ResidualTransformer (model.py:17-18,28,31 of that plugin).
+extern "C" int tup_layernorm128_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
+                                    int M, void* stream)
+{
+    if (M <= 0) return 0;
+    int blocks = (M + 15) / 16;
+    if (blocks > 1024) blocks = 1024;
+    layernorm_bwd_kernel<2><<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
     TUP_CHECK_LAUNCH();
     return 0;

@@ -15,14 +15,15 @@ TUP_DEVICE s16x4 lds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-TUP_DEVICE void stage_x_halo(char* lds, const bf16_t* xb, int H, int W, int ty0, int tx0, int tid) {
+// xr > 1: x is [H*xr][W*xr][64] and the tile reads its (xsi, xsj) space-to-depth plane (stride-xr conv input)
+TUP_DEVICE void stage_x_halo(char* lds, const bf16_t* xb, int H, int W, int ty0, int tx0, int tid, int xr = 1, int xsi = 0, int xsj = 0) {
     for (int idx = tid; idx < NPIX_HALO * 8; idx += 256) {
         const int q = idx >> 3, c = idx & 7;
         const int yy = q / HALO_W, xx = q - yy * HALO_W;
         const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-            v = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * 64 + c * 8);
+            v = *reinterpret_cast<const u32x4*>(xb + ((size_t)(iy * xr + xsi) * (W * xr) + (ix * xr + xsj)) * 64 + c * 8);
         *reinterpret_cast<u32x4*>(lds + swz128(q, c)) = v;
     }
 }
@@ -35,7 +36,7 @@ TUP_DEVICE void stage_x_halo(char* lds, const bf16_t* xb, int H, int W, int ty0,
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gmap, float* __restrict__ dwp, float* __restrict__ dbias,
-    int B, int H, int W, int gr, int sp, int tilesX, int tilesY)
+    int B, int H, int W, int gr, int sp, int tilesX, int tilesY, int xr, int xsp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* x_lds = smem;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
         const int ty = t % tilesY;
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
-        stage_x_halo(x_lds, x + (size_t)b * H * W * 64, H, W, ty0, tx0, tid);
+        stage_x_halo(x_lds, x + (size_t)b * H * W * 64 * xr * xr, H, W, ty0, tx0, tid, xr, xsp / xr, xsp % xr);
         const bf16_t* gb = gmap + (size_t)b * Hg * Wg * 64;
         for (int idx = tid; idx < 256 * 8; idx += 256) {
             const int pix = idx >> 3, c = idx & 7;
@@ -469,13 +470,11 @@ int persistent_grid(long long ntiles, int per_cu) {
 
 }  // namespace
 
-// dwp fp32 [64][9][64] (co, tap, ci) +=, dbias fp32 [64] += (or NULL).  x NHWC bf16 [B][H][W][64];
-// gmap NHWC bf16 [B][H*gr][W*gr][64], sub-pixel plane sp (gr = 1, sp = 0: plain).
-extern "C" int tup_conv3x3_c64_wgrad(const void* x, const void* gmap, float* dwp, float* dbias,
-                                     int B, int H, int W, int gr, int sp, void* stream)
+static int conv_c64_wgrad_launch(const void* x, const void* gmap, float* dwp, float* dbias,
+                                 int B, int H, int W, int gr, int sp, int xr, int xsp, void* stream)
 {
     if (B <= 0) return 0;
-    if (gr < 1 || sp < 0 || sp >= gr * gr) return (int)hipErrorInvalidValue;
+    if (gr < 1 || sp < 0 || sp >= gr * gr || xr < 1 || xsp < 0 || xsp >= xr * xr) return (int)hipErrorInvalidValue;
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -487,9 +486,26 @@ extern "C" int tup_conv3x3_c64_wgrad(const void* x, const void* gmap, float* dwp
         attr_set = true;
     }
     conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, 2)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)x, (const bf16_t*)gmap, dwp, dbias, B, H, W, gr, sp, tilesX, tilesY);
+        (const bf16_t*)x, (const bf16_t*)gmap, dwp, dbias, B, H, W, gr, sp, tilesX, tilesY, xr, xsp);
     TUP_CHECK_LAUNCH();
     return 0;
+}
+
+// dwp fp32 [64][9][64] (co, tap, ci) +=, dbias fp32 [64] += (or NULL).  x NHWC bf16 [B][H][W][64];
+// gmap NHWC bf16 [B][H*gr][W*gr][64], sub-pixel plane sp (gr = 1, sp = 0: plain).
+extern "C" int tup_conv3x3_c64_wgrad(const void* x, const void* gmap, float* dwp, float* dbias,
+                                     int B, int H, int W, int gr, int sp, void* stream)
+{
+    return conv_c64_wgrad_launch(x, gmap, dwp, dbias, B, H, W, gr, sp, 1, 0, stream);
+}
+
+// Weight gradient of a stride-xr conv seen as a 3x3 conv over the space-to-depth input (packing.pack_conv_c64_stride2):
+// x NHWC bf16 [B][H*xr][W*xr][64], plane xsp = si*xr + sj; gmap NHWC bf16 [B][H][W][64]; dwp as above (the block taps
+// of that plane), dbias or NULL.
+extern "C" int tup_conv3x3_c64_wgrad_s2d(const void* x, const void* gmap, float* dwp, float* dbias,
+                                         int B, int H, int W, int xr, int xsp, void* stream)
+{
+    return conv_c64_wgrad_launch(x, gmap, dwp, dbias, B, H, W, 1, 0, xr, xsp, stream);
 }
 
 // thin conv (cout 3): gpl fp32 [B][3][H][W]; dwp fp32 [3][9][64] +=, dbias fp32 [3] += (or NULL).

@@ -22,6 +22,7 @@ struct WgradParams {
     float* out; int ldo;         // [NI][NJ] fp32, accumulated
     int M, NI, NJ, mchunk;
     int H, W, Ht, Wt_, nWx, nWy, reflect;   // OP_PATCH geometry (token rows in window layout)
+    int linear;                             // OP_PATCH: token rows are a plain [B][Ht][Wt] grid (ResidualTransformer)
 };
 
 TUP_DEVICE s16x4 lds_read_tr16(const char* p) {
@@ -58,12 +59,20 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
     auto load_patch = [&](int m, u32x4* r) {
         // column block j0 = patch pixel (i, j); 64 channels
         bool ok = m < mend;
-        const int tok = m & 63;
-        int win = m >> 6;
-        const int wx = win % p.nWx; win /= p.nWx;
-        const int wy = win % p.nWy;
-        const int b = win / p.nWy;
-        const int ty = wy * 8 + (tok >> 3), tx = wx * 8 + (tok & 7);
+        int b, ty, tx;
+        if (p.linear) {
+            const int per = p.Ht * p.Wt_;
+            b = m / per;
+            const int rem = m - b * per;
+            ty = rem / p.Wt_; tx = rem - ty * p.Wt_;
+        } else {
+            const int tok = m & 63;
+            int win = m >> 6;
+            const int wx = win % p.nWx; win /= p.nWx;
+            const int wy = win % p.nWy;
+            b = win / p.nWy;
+            ty = wy * 8 + (tok >> 3); tx = wx * 8 + (tok & 7);
+        }
         ok = ok && ty < p.Ht && tx < p.Wt_;
         const int pix = j0 >> 6;
         int py = ty * 8 + (pix >> 3), px = tx * 8 + (pix & 7);
@@ -226,6 +235,18 @@ extern "C" int tup_patch_wgrad(const float* P, const void* map, float* out, int 
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8; p.reflect = reflect;
     p.P = P; p.ldp = 192; p.Q = map; p.out = out; p.ldo = 4096;
     p.M = B * p.nWy * p.nWx * 64; p.NI = 192; p.NJ = 4096;
+    return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ResidualTransformer's patch_embed / patch_unembed weights: out[128][4096] += P^T patches(map), P fp32 [B*T][128]
+// on the plain token grid (H, W multiples of 8).
+extern "C" int tup_rt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, void* stream)
+{
+    if (H % 8 || W % 8) return (int)hipErrorInvalidValue;
+    WgradParams p{};
+    p.H = H; p.W = W; p.Ht = H / 8; p.Wt_ = W / 8; p.linear = 1; p.reflect = 0;
+    p.P = P; p.ldp = 128; p.Q = map; p.out = out; p.ldo = 4096;
+    p.M = B * p.Ht * p.Wt_; p.NI = 128; p.NJ = 4096;
     return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -12,8 +12,10 @@ namespace {
 constexpr int RD = 128, RH = 8, HD = 16;
 
 // ---- flash-style attention, one wave per (batch, head, 64-query tile); S^T tiles in registers, online softmax ----
+template <bool DROP>
 __global__ __launch_bounds__(256) void rt_attention_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int B, int N, int qtiles)
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int B, int N, int qtiles,
+    uint32_t thresh, float inv_keep, uint32_t seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[4][64 * HD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -27,6 +29,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
     const int b = wid / (qtiles * RH);
     const bf16_t* base = qkv + (size_t)b * N * (3 * RD) + h * HD;
     const int q0 = qt0 * 64;
+    const uint32_t hseed = seed + (uint32_t)(b * RH + h) * 0x9E3779B9u;      // dropout stream of this (image, head)
 
     s16x4 qf[4];
 #pragma unroll
@@ -96,6 +99,11 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
                 float pv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { pv[e] = __expf(st[kt][qt][e] - mx); sum += pv[e]; }
+                if constexpr (DROP) {       // nn.MultiheadAttention drops the normalised probabilities: l keeps the full sum
+                    const uint32_t qi = (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + 4 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] *= drop_scale(hseed, qi + e, thresh, inv_keep);
+                }
                 const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
                 o = mfma16x16x16(vf[kt], __builtin_bit_cast(s16x4, pp), o);
             }
@@ -121,7 +129,8 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
 }
 
 __global__ __launch_bounds__(256) void layernorm128_kernel(
-    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y, int M)
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int M)
 {
     const int sub = threadIdx.x & 15;                   // 16 lanes per row, 8 elements per lane
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -146,6 +155,7 @@ __global__ __launch_bounds__(256) void layernorm128_kernel(
     for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
     const float rstd = rsqrtf(ss * (1.0f / RD) + 1e-5f);
     if (!ok) return;
+    if (mean_out && sub == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int c = q * 64 + sub * 4;
@@ -228,9 +238,11 @@ TUP_DEVICE void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ go, const float* __restrict__ lse,
-    const float* __restrict__ dsum, bf16_t* __restrict__ gqkv, int B, int N, int tiles)
+    const float* __restrict__ dsum, bf16_t* __restrict__ gqkv, int B, int N, int tiles,
+    uint32_t thresh, float inv_keep, uint32_t seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t klds[4][64 * HD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
     const bf16_t* base = qkv + (size_t)b * N * (3 * RD) + h * HD;
     const bf16_t* gbase = go + (size_t)b * N * RD + h * HD;
     const int q0 = qt0 * 64;
+    const uint32_t hseed = seed + (uint32_t)(b * RH + h) * 0x9E3779B9u;
     s16x4 qf[4], dof[4];
     float lc[4], dc[4];
 #pragma unroll
@@ -291,7 +304,9 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + 16 * kt + 4 * g + e;
                     const float pr = key < N ? __expf(s[e] * 0.25f - lc[qt]) : 0.f;
-                    ds[e] = pr * (dp[e] - dc[qt]);
+                    float dpe = dp[e];
+                    if constexpr (DROP) dpe *= drop_scale(hseed, (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)key, thresh, inv_keep);
+                    ds[e] = pr * (dpe - dc[qt]);
                 }
                 dq[qt] = mfma16x16x16(kT[kt], f4_to_bf16x4(ds), dq[qt]);
             }
@@ -307,9 +322,11 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
     }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ go, const float* __restrict__ lse,
-    const float* __restrict__ dsum, bf16_t* __restrict__ gqkv, int B, int N, int tiles)
+    const float* __restrict__ dsum, bf16_t* __restrict__ gqkv, int B, int N, int tiles,
+    uint32_t thresh, float inv_keep, uint32_t seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4][2][64 * HD];          // per wave: Q tile, dO tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
     const float* lrow = lse + ((size_t)b * RH + h) * N;
     const float* drow = dsum + ((size_t)b * RH + h) * N;
     const int k0 = kt0 * 64;
+    const uint32_t hseed = seed + (uint32_t)(b * RH + h) * 0x9E3779B9u;
     s16x4 kf[4], vf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -381,7 +399,14 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
                 for (int e = 0; e < 4; ++e) {
                     const int qq = q0 + 16 * qt + 4 * g + e;
                     pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
-                    ds[e] = pr[e] * (dp[e] - dr[qt][e]);
+                    float dpe = dp[e];
+                    float keep = 1.0f;
+                    if constexpr (DROP) {
+                        keep = drop_scale(hseed, (uint32_t)qq * (uint32_t)N + (uint32_t)(k0 + 16 * kt + p), thresh, inv_keep);
+                        dpe *= keep;
+                    }
+                    ds[e] = pr[e] * (dpe - dr[qt][e]);
+                    pr[e] *= keep;                       // dV sees the dropped probabilities
                 }
                 dvT[kt] = mfma16x16x16(doT[qt], f4_to_bf16x4(pr), dvT[kt]);
                 dkT[kt] = mfma16x16x16(qT[qt], f4_to_bf16x4(ds), dkT[kt]);
@@ -399,25 +424,72 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
     }
 }
 
+// Backward of out = clamp(bicubic(a) + bicubic(b)) w.r.t. a, separable, in gather form: the clamp gate is read from
+// the saved output (0 < out < 1), pass 1 reduces output rows onto source rows (CSR lists per source row: which
+// output rows touch it and with what weight), pass 2 does the same along x.
+__global__ __launch_bounds__(256) void rt_bicubic_bwd_rows_kernel(
+    const float* __restrict__ gout, const float* __restrict__ out, float* __restrict__ tmp,
+    const int* __restrict__ ystart, const int* __restrict__ yo, const float* __restrict__ yw, int Ha, int Ho, int Wo)
+{
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, plane = blockIdx.z;
+    if (ox >= Wo) return;
+    const int t0 = ystart[y], t1 = ystart[y + 1];
+    const float* gp = gout + (size_t)plane * Ho * Wo + ox;
+    const float* op = out ? out + (size_t)plane * Ho * Wo + ox : nullptr;
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const size_t off = (size_t)yo[t] * Wo;
+        float gv = gp[off];
+        if (op) { const float o = op[off]; gv = (o > 0.f && o < 1.f) ? gv : 0.f; }
+        acc += yw[t] * gv;
+    }
+    tmp[((size_t)plane * Ha + y) * Wo + ox] = acc;
+}
+
+__global__ __launch_bounds__(256) void rt_bicubic_bwd_cols_kernel(
+    const float* __restrict__ tmp, float* __restrict__ ga, const int* __restrict__ xstart, const int* __restrict__ xo,
+    const float* __restrict__ xw, int Ha, int Wa, int Wo)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, plane = blockIdx.z;
+    if (x >= Wa) return;
+    const float* tp = tmp + ((size_t)plane * Ha + y) * Wo;
+    float acc = 0.f;
+    for (int t = xstart[x]; t < xstart[x + 1]; ++t) acc += xw[t] * tp[xo[t]];
+    ga[((size_t)plane * Ha + y) * Wa + x] = acc;
+}
+
 }  // namespace
 
 // qkv bf16 [B][N][384] (q | k | v, each 8 heads x 16); out bf16 [B][N][128]; lse fp32 [B][8][N] (optional: log-sum-exp
 // of the scaled scores per query, saved for the backward).  Eval-mode attention (no dropout).
-extern "C" int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, void* stream)
+extern "C" int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, float drop_p,
+                                    unsigned int drop_seed, void* stream)
 {
+    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     if (B <= 0 || N <= 0) return 0;
     const int qtiles = (N + 63) / 64;
     const long long waves = (long long)B * RH * qtiles;
-    rt_attention_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, qtiles);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (drop_p > 0.f)
+        rt_attention_kernel<true><<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+            (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, qtiles, thresh, inv_keep, drop_seed);
+    else
+        rt_attention_kernel<false><<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+            (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, qtiles, 0u, 1.0f, 0u);
     TUP_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int tup_layernorm128_fwd(const float* x, const float* gamma, const float* beta, void* y, int M, void* stream)
+extern "C" int tup_layernorm128_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                    int M, void* stream)
 {
     if (M <= 0) return 0;
-    layernorm128_kernel<<<dim3((M + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(x, gamma, beta, (bf16_t*)y, M);
+    if ((mean == nullptr) != (rstd == nullptr)) return (int)hipErrorInvalidValue;
+    layernorm128_kernel<<<dim3((M + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(x, gamma, beta, (bf16_t*)y, mean, rstd, M);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -441,9 +513,12 @@ extern "C" int tup_rt_bicubic_sum_fwd(const float* a, const float* b, float* out
 // Backward of tup_rt_attention_fwd: qkv bf16 [B][N][384], out (forward output) and gout bf16 [B][N][128], lse fp32
 // [B][8][N]; work fp32 [B][8][N] scratch; gqkv bf16 [B][N][384] (overwritten).
 extern "C" int tup_rt_attention_bwd(const void* qkv, const void* out, const void* gout, const float* lse, float* work,
-                                    void* gqkv, int B, int N, void* stream)
+                                    void* gqkv, int B, int N, float drop_p, unsigned int drop_seed, void* stream)
 {
     if (B <= 0 || N <= 0) return 0;
+    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const float inv_keep = 1.0f / (1.0f - drop_p);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long nprep = (long long)B * N * RH;
     rt_attn_bwd_prep_kernel<<<dim3((unsigned)((nprep + 255) / 256)), dim3(256), 0, s>>>((const bf16_t*)out, (const bf16_t*)gout, work, B, N);
@@ -451,9 +526,33 @@ extern "C" int tup_rt_attention_bwd(const void* qkv, const void* out, const void
     const int tiles = (N + 63) / 64;
     const long long waves = (long long)B * RH * tiles;
     const unsigned grid = (unsigned)((waves + 3) / 4);
-    rt_attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles);
+    if (drop_p > 0.f) {
+        rt_attn_bwd_dq_kernel<true><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles, thresh, inv_keep, drop_seed);
+        TUP_CHECK_LAUNCH();
+        rt_attn_bwd_dkv_kernel<true><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles, thresh, inv_keep, drop_seed);
+        TUP_CHECK_LAUNCH();
+    } else {
+        rt_attn_bwd_dq_kernel<false><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles, 0u, 1.0f, 0u);
+        TUP_CHECK_LAUNCH();
+        rt_attn_bwd_dkv_kernel<false><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles, 0u, 1.0f, 0u);
+        TUP_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// Backward of tup_rt_bicubic_sum_fwd w.r.t. its first source `a`: gout / out fp32 [planes][Ho][Wo] (out = the saved
+// forward output; NULL = no clamp gate), ga fp32 [planes][Ha][Wa], tmp fp32 [planes][Ha][Wo] scratch.  ystart [Ha+1] /
+// yo / yw and xstart [Wa+1] / xo / xw are the transposed tap lists (per source row / column: the outputs it feeds).
+extern "C" int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga, float* tmp, const int* ystart, const int* yo,
+                                  const float* yw, const int* xstart, const int* xo, const float* xw, int planes, int Ha, int Wa,
+                                  int Ho, int Wo, void* stream)
+{
+    if (planes <= 0) return 0;
+    if (planes > 65535 || Ha > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rt_bicubic_bwd_rows_kernel<<<dim3((Wo + 255) / 256, Ha, planes), dim3(256), 0, s>>>(gout, out, tmp, ystart, yo, yw, Ha, Ho, Wo);
     TUP_CHECK_LAUNCH();
-    rt_attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles);
+    rt_bicubic_bwd_cols_kernel<<<dim3((Wa + 255) / 256, Ha, planes), dim3(256), 0, s>>>(tmp, ga, xstart, xo, xw, Ha, Wa, Wo);
     TUP_CHECK_LAUNCH();
     return 0;
 }

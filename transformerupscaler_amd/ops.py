@@ -448,28 +448,84 @@ def rt_patch_unembed(x, wt, bias, skip):
     return out
 
 
-def rt_attention(qkv, B, N, save_lse=False):
+def rt_attention(qkv, B, N, save_lse=False, drop_p=0.0, drop_seed=0):
     out = torch.empty((B * N, 128), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, 8, N), dtype=F32, device=qkv.device) if save_lse else None
     _lib.call("tup_rt_attention_fwd", _chk(qkv, BF16, (B * N, 384), "qkv"), out.data_ptr(),
-              None if lse is None else lse.data_ptr(), B, N, _stream())
+              None if lse is None else lse.data_ptr(), B, N, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     return (out, lse) if save_lse else out
 
 
-def rt_attention_bwd(qkv, out, gout, lse, B, N):
+def rt_attention_bwd(qkv, out, gout, lse, B, N, drop_p=0.0, drop_seed=0):
     gqkv = torch.empty((B * N, 384), dtype=BF16, device=qkv.device)
     work = torch.empty((B, 8, N), dtype=F32, device=qkv.device)
     _lib.call("tup_rt_attention_bwd", _chk(qkv, BF16, (B * N, 384), "qkv"), _chk(out, BF16, (B * N, 128), "out"),
-              _chk(gout, BF16, (B * N, 128), "gout"), _chk(lse, F32, (B, 8, N), "lse"), work.data_ptr(), gqkv.data_ptr(), B, N, _stream())
+              _chk(gout, BF16, (B * N, 128), "gout"), _chk(lse, F32, (B, 8, N), "lse"), work.data_ptr(), gqkv.data_ptr(), B, N,
+              float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     return gqkv
 
 
-def layernorm128(x, gamma, beta):
+def layernorm128(x, gamma, beta, save_stats=False):
     M = x.shape[0]
     y = torch.empty((M, 128), dtype=BF16, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty((M,), dtype=F32, device=x.device)
+        rstd = torch.empty((M,), dtype=F32, device=x.device)
     _lib.call("tup_layernorm128_fwd", _chk(x, F32, (M, 128), "x"), _chk(gamma, F32, (128,), "gamma"), _chk(beta, F32, (128,), "beta"),
-              y.data_ptr(), M, _stream())
-    return y
+              y.data_ptr(), None if mean is None else mean.data_ptr(), None if rstd is None else rstd.data_ptr(), M, _stream())
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm128_bwd(gy, x, mean, rstd, gamma, gres=None):
+    M = x.shape[0]
+    dx = torch.empty((M, 128), dtype=F32, device=x.device)
+    dg = torch.zeros((128,), dtype=F32, device=x.device)
+    db = torch.zeros((128,), dtype=F32, device=x.device)
+    _lib.call("tup_layernorm128_bwd", _chk(gy, BF16, (M, 128), "gy"), _chk(x, F32, (M, 128), "x"), _chk(mean, F32, (M,), "mean"),
+              _chk(rstd, F32, (M,), "rstd"), _chk(gamma, F32, (128,), "gamma"), _opt(gres, F32, (M, 128), "gres"),
+              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, _stream())
+    return dx, dg, db
+
+
+def rt_patch_wgrad(p, fmap):
+    """fp32 [128][4096] = p^T patches(fmap); p fp32 [B*T][128] (plain token grid), fmap NHWC bf16."""
+    B, H, W, C = fmap.shape
+    out = torch.zeros((128, 4096), dtype=F32, device=p.device)
+    _lib.call("tup_rt_patch_wgrad", _chk(p, F32, (B * (H // 8) * (W // 8), 128), "p"), _chk(fmap, BF16, None, "map"),
+              out.data_ptr(), B, H, W, _stream())
+    return out
+
+
+def rt_patch_unembed_bwd(gmap, wd):
+    """d tokens fp32 [B*T][128] of patch_unembed: the patch_embed GEMM with the transposed weight (no bias / pos)."""
+    B, H, W, C = gmap.shape
+    x = torch.empty((B * (H // 8) * (W // 8), 128), dtype=F32, device=gmap.device)
+    _lib.call("tup_rt_patch_embed_fwd", _chk(gmap, BF16, None, "gmap"), _chk(wd, BF16, (128, 4096), "wd"), None, None,
+              x.data_ptr(), B, H, W, _stream())
+    return x
+
+
+def rt_patch_embed_bwd(gx, wd, add):
+    """d feat_down NHWC bf16 = add + scatter(gx wd^T): the patch_unembed GEMM with the transposed weight; `add` carries
+    the gradient of the skip connection (model.py:153)."""
+    B, H, W, C = add.shape
+    out = torch.empty_like(add)
+    _lib.call("tup_rt_patch_unembed_fwd", _chk(gx, F32, (B * (H // 8) * (W // 8), 128), "gx"), _chk(wd, BF16, (4096, 128), "wd"),
+              None, _chk(add, BF16, None, "add"), out.data_ptr(), B, H, W, _stream())
+    return out
+
+
+def conv_c64_wgrad_s2d(x, gmap, xr):
+    """Stride-xr conv weight gradient: fp32 [xr*xr][64 co][9][64 ci] block-tap gradients + bias gradient [64]."""
+    B, H, W, C = gmap.shape
+    assert tuple(x.shape) == (B, H * xr, W * xr, 64)
+    dwp = torch.zeros((xr * xr, 64, 9, 64), dtype=F32, device=x.device)
+    db = torch.zeros((64,), dtype=F32, device=x.device)
+    for sp in range(xr * xr):
+        _lib.call("tup_conv3x3_c64_wgrad_s2d", _chk(x, BF16, None, "x"), _chk(gmap, BF16, None, "gmap"), dwp[sp].data_ptr(),
+                  db.data_ptr() if sp == 0 else None, B, H, W, xr, sp, _stream())
+    return dwp, db
 
 
 _BIC_CACHE = {}
@@ -482,6 +538,32 @@ def _bicubic_on(device, in_size, out_size):
         idx, w = bicubic_taps(in_size, out_size)
         _BIC_CACHE[key] = (torch.from_numpy(idx).to(device), torch.from_numpy(w).to(device))
     return _BIC_CACHE[key]
+
+
+_BICT_CACHE = {}
+
+
+def _bicubic_t_on(device, in_size, out_size):
+    key = (str(device), in_size, out_size)
+    if key not in _BICT_CACHE:
+        from .resize_taps import bicubic_taps, transpose_taps
+        idx, w = bicubic_taps(in_size, out_size)
+        _BICT_CACHE[key] = tuple(torch.from_numpy(t).to(device) for t in transpose_taps(idx, w, in_size))
+    return _BICT_CACHE[key]
+
+
+def rt_bicubic_bwd(gout, out, in_hw):
+    """Gradient of clamp(bicubic(src -> size) + ...) w.r.t. a planar fp32 source of size in_hw; `out` = the saved
+    forward output (the clamp gate) or None."""
+    B, C, Ho, Wo = gout.shape
+    Ha, Wa = in_hw
+    ys, yo, yw = _bicubic_t_on(gout.device, Ha, Ho)
+    xs, xo, xw = _bicubic_t_on(gout.device, Wa, Wo)
+    ga = torch.empty((B, C, Ha, Wa), dtype=F32, device=gout.device)
+    tmp = torch.empty((B, C, Ha, Wo), dtype=F32, device=gout.device)
+    _lib.call("tup_rt_bicubic_bwd", _chk(gout, F32, None, "gout"), _opt(out, F32, (B, C, Ho, Wo), "out"), ga.data_ptr(), tmp.data_ptr(),
+              ys.data_ptr(), yo.data_ptr(), yw.data_ptr(), xs.data_ptr(), xo.data_ptr(), xw.data_ptr(), B * C, Ha, Wa, Ho, Wo, _stream())
+    return ga
 
 
 def rt_bicubic_sum(a, b, size, clamp=True):

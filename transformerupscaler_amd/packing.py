@@ -217,7 +217,37 @@ def pack_conv_c64_stride2(weight: torch.Tensor, bias):
     return w.unsqueeze(0).contiguous().to(torch.bfloat16), b
 
 
-def pack_rt_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+def pack_conv_c64_stride2_dgrad(weight: torch.Tensor):
+    """Input-gradient conv of Conv2d(64, 64, 3, stride=2, padding=1): a 3x3 conv over the output gradient with one
+    output tile per input sub-pixel (si, sj), stored through PixelShuffle(2).  Block tap (dy, dx) of sub-pixel (si, sj)
+    carries original tap ky = si + 1 - 2(dy - 1) (same in x) when that lies in 0..2.  bf16 [4][1][9][64 = ci][64 = co]."""
+    assert tuple(weight.shape) == (64, 64, 3, 3)
+    w = torch.zeros(4, 9, 64, 64, dtype=weight.dtype, device=weight.device)          # [sub-pixel][tap][ci][co]
+    for si in range(2):
+        for sj in range(2):
+            for dy in range(3):
+                for dx in range(3):
+                    ky, kx = si + 1 - 2 * (dy - 1), sj + 1 - 2 * (dx - 1)
+                    if 0 <= ky <= 2 and 0 <= kx <= 2:
+                        w[si * 2 + sj, dy * 3 + dx] = weight[:, :, ky, kx].t()
+    w = w.index_select(2, _PERM64.to(w.device))
+    return w.unsqueeze(1).contiguous().to(torch.bfloat16)
+
+
+def unpack_conv_c64_stride2_wgrad(dwp: torch.Tensor):
+    """[4 planes][64 co][9 block taps][64 ci] -> reference layout [64][64][3][3] (inverse of pack_conv_c64_stride2)."""
+    dw = torch.zeros(64, 64, 3, 3, dtype=dwp.dtype, device=dwp.device)
+    for si in range(2):
+        for sj in range(2):
+            for dy in range(3):
+                for dx in range(3):
+                    ky, kx = 2 * (dy - 1) + si + 1, 2 * (dx - 1) + sj + 1
+                    if 0 <= ky <= 2 and 0 <= kx <= 2:
+                        dw[:, :, ky, kx] = dwp[si * 2 + sj, :, dy * 3 + dx, :]
+    return dw
+
+
+def pack_rt_state_dict(sd: Dict[str, torch.Tensor], backward: bool = False) -> Dict[str, torch.Tensor]:
     pk: Dict[str, torch.Tensor] = {}
     f32 = lambda t: t.detach().float().contiguous()
     t = lambda k: sd[k].detach()
@@ -240,4 +270,16 @@ def pack_rt_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     pk["pu.w"] = pack_linear(t("patch_unembed.weight").permute(2, 3, 1, 0).reshape(4096, 128)); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(t("decoder_conv1.weight"), t("decoder_conv1.bias"), 1)
     pk["dec2.w"] = pack_conv_c64_thin(t("decoder_conv2.weight")); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])
+    if not backward:
+        return pk
+    pk["conv2.wd"] = pack_conv_c64_dgrad(t("conv2.weight"), 1)
+    pk["ds.wd"] = pack_conv_c64_stride2_dgrad(t("downsample.weight"))
+    pk["dec1.wd"] = pack_conv_c64_dgrad(t("decoder_conv1.weight"), 1)
+    pk["dec2.wd"] = pack_conv_thin_dgrad(t("decoder_conv2.weight"))
+    pk["pe.wd"] = pack_linear(t("patch_embed.weight").permute(2, 3, 1, 0).reshape(4096, 128))     # rows (i,j,c), cols n
+    pk["pu.wd"] = pack_linear(t("patch_unembed.weight").permute(0, 2, 3, 1).reshape(128, 4096))   # rows k, cols (i,j,o)
+    for i in range(nb):
+        p = f"transformer_blocks.{i}"
+        for nm, key in (("in", "attn.in_proj_weight"), ("out", "attn.out_proj.weight"), ("fc1", "mlp.0.weight"), ("fc2", "mlp.2.weight")):
+            pk[f"b{i}.{nm}.wd"] = pack_linear(t(f"{p}.{key}").t().contiguous())
     return pk

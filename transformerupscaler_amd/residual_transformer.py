@@ -3,8 +3,9 @@ BASELINE.json config 5) on the MI355X HIP kernels -- forward / inference path.
 
 Same constructor keywords, forward signature and state_dict keys as the reference (incl. nn.MultiheadAttention's
 packed ``attn.in_proj_weight`` / ``attn.out_proj``).  Like the reference it only accepts inputs whose token grid has
-3600 tokens (720x1280): ``tokens + pos_embed`` (model.py:140) fixes the sequence length.  The training
-(backward) path of this variant is not built yet; calling it with gradients enabled raises.
+3600 tokens (720x1280): ``tokens + pos_embed`` (model.py:140) fixes the sequence length.  With gradients enabled
+the call goes through autograd_rt (hand-written backward; dropout in ``.train()`` mode as stateless hash masks on the
+attention probabilities and the MLP output, reference model.py:30,37).
 """
 from __future__ import annotations
 
@@ -58,13 +59,25 @@ class TransformerModel(nn.Module):
         self.patch_unembed = _ConvParams(transformer_dim, base_channels, 8, transposed=True)
         self.decoder_conv1 = _ConvParams(base_channels, base_channels, 3)
         self.decoder_conv2 = _ConvParams(base_channels, in_channels, 3)
-        self._pack_cache = None
+        self._pack_cache = {}
+        self._dropout_calls = 0
 
-    def packed(self):
+    def _next_dropout(self):
+        """(p, seed) of the next training forward (see fast_transformer.TransformerModel._next_dropout)."""
+        if not self.training or self.dropout_p <= 0.0:
+            return 0.0, 0
+        import os
+        self._dropout_calls += 1
+        base = (torch.initial_seed() + 7919 * int(os.environ.get("RANK", "0"))) & 0x7FFFFFFF
+        return self.dropout_p, (base * 2654435761 + self._dropout_calls) & 0xFFFFFFFF
+
+    def packed(self, backward: bool = False):
         ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if self._pack_cache is None or self._pack_cache[0] != ver:
-            self._pack_cache = (ver, packing.pack_rt_state_dict(dict(self.named_parameters())))
-        return self._pack_cache[1]
+        hit = self._pack_cache.get(bool(backward))
+        if hit is None or hit[0] != ver:
+            hit = (ver, packing.pack_rt_state_dict(dict(self.named_parameters()), backward=backward))
+            self._pack_cache[bool(backward)] = hit
+        return hit[1]
 
     def forward(self, x: torch.Tensor, res_out: Tuple[int, int] = (1080, 1920), upscale_factor: Optional[int] = None,
                 require_ratio: bool = True) -> torch.Tensor:
@@ -78,7 +91,11 @@ class TransformerModel(nn.Module):
             raise RuntimeError(f"input {H}x{W} gives {(hd // 8) * (wd // 8)} tokens; pos_embed has {self.num_tokens} "
                                "(the reference fails the same way at model.py:140)")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("ResidualTransformer: only the inference path is built; wrap the call in torch.no_grad()")
+            from .autograd_rt import residual_transformer_function
+            out = residual_transformer_function(self, x, tuple(int(v) for v in res_out))
+            return out.to(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else out
+        if self.training and self.dropout_p > 0.0:
+            raise NotImplementedError("ResidualTransformer: .train() forward without gradients is not built; use .eval() under no_grad")
         pk = self.packed()
         x = x.contiguous().float()
         feat = ops.conv_c64(ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True), pk["conv2.w"], pk["conv2.b"], 1, relu=True)

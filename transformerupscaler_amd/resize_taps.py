@@ -92,3 +92,17 @@ def bicubic_taps(in_size: int, out_size: int):
     w = np.stack([c2(t + f(1)), c1(t), c1(f(1) - t), c2(f(2) - t)], axis=1).astype(np.float32)
     idx = np.clip(fl.astype(np.int64)[:, None] - 1 + np.arange(4)[None, :], 0, in_size - 1).astype(np.int32)
     return np.ascontiguousarray(idx), np.ascontiguousarray(w)
+
+
+def transpose_taps(idx: np.ndarray, w: np.ndarray, in_size: int):
+    """Per-output tap lists (idx, w: [out][K]) -> per-source CSR lists for the gather-form backward:
+    start int32 [in+1], out_index int32 [nnz], weight float32 [nnz] (taps clamped onto the same source stay separate
+    entries, so the backward adds exactly the terms the forward used)."""
+    out_size, K = idx.shape
+    flat_src = idx.reshape(-1).astype(np.int64)
+    flat_out = np.repeat(np.arange(out_size, dtype=np.int64), K)
+    order = np.argsort(flat_src, kind="stable")
+    counts = np.bincount(flat_src, minlength=in_size)
+    start = np.zeros(in_size + 1, dtype=np.int32)
+    start[1:] = np.cumsum(counts)
+    return start, np.ascontiguousarray(flat_out[order].astype(np.int32)), np.ascontiguousarray(w.reshape(-1)[order].astype(np.float32))

@@ -60,7 +60,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="inference images per GPU per step")
     ap.add_argument("--train-batch", type=int, default=4, help="training images per GPU per step (config 3: 32 / 8 GPUs)")
-    ap.add_argument("--mode", choices=["infer", "train", "both"], default="both")
+    ap.add_argument("--rt-batch", type=int, default=2, help="ResidualTransformer 6x training images per GPU per step (config 5: 16 / 8 GPUs)")
+    ap.add_argument("--mode", choices=["infer", "train", "rt", "both"], default="both",
+                    help="both = headline inference + FastTransformer training step + ResidualTransformer 6x training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,7 +142,62 @@ def main():
                 "parallelism": f"dp{world}" + (" RCCL all-reduce of 17.9 MB fp32 grads in ~6 MB buckets, overlapped with backward" if world > 1 else ""),
                 "optimizer": "Adam lr 1e-4 (torch.optim)", "loss_fn": "L1 vs synthetic HR after antialiased resize 1440x2560 -> 1080x1920"}
 
+    def run_rt_train():
+        """BASELINE.json configs[4]: ResidualTransformer 6x (720p -> 4320x7680) bf16 training step, 2 images/GPU, DP."""
+        import torch.nn.functional as F
+        from transformerupscaler_amd.dp import DataParallel
+        from transformerupscaler_amd.weights import rt_deterministic_state_dict
+        tm = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
+        tm.load_state_dict(rt_deterministic_state_dict(0))
+        tm = tm.to(dev).train()                     # dropout p=0.1 on attention probabilities and MLP output
+        dp = DataParallel(tm) if world > 1 else None
+        opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
+        gt = torch.Generator().manual_seed(9876 + rank)
+        lr = torch.rand((args.rt_batch, 3, LR_H, LR_W), generator=gt).to(dev)
+        hr = torch.rand((args.rt_batch, 3, LR_H * 6, LR_W * 6), generator=gt).to(dev)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = F.l1_loss(tm(lr, upscale_factor=6), hr)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
+        steps = max(1, min(args.steps, 10))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        barrier()
+        dtt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dtt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtt = float(t.item())
+        del dp
+        return {"metric": "images/sec, ResidualTransformer 6x 720p->4320x7680 training step", "value": world * args.rt_batch * steps / dtt,
+                "unit": "images/sec", "ms_per_step": dtt / steps * 1e3, "steps": steps, "images_per_gpu_per_step": args.rt_batch,
+                "global_batch": world * args.rt_batch, "loss": float(loss.item()), "dropout": "p=0.1 (train mode, stateless hash masks)",
+                "parallelism": f"dp{world}" + (" RCCL all-reduce of 12.8 MB fp32 grads, overlapped with backward" if world > 1 else ""),
+                "optimizer": "Adam lr 1e-4 (torch.optim)", "loss_fn": "L1 vs synthetic 4320x7680 HR"}
+
     train_result = run_train() if args.mode in ("train", "both") else None
+    rt_result = run_rt_train() if args.mode in ("rt", "both") else None
+    if args.mode == "rt":
+        if rank == 0:
+            out = dict(rt_result)
+            out.update({"n_gpus": world, "warmup": 2, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "dtype": "bf16", "data": "synthetic",
+                        "config": {"workload": "ResidualTransformer 6x 720x1280 -> 4320x7680 bf16 training step (BASELINE.json configs[4])"}})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.mode == "train":
         if rank == 0:
             out = dict(train_result)
@@ -206,6 +263,8 @@ def main():
         }
         if train_result is not None:
             out["train"] = train_result
+        if rt_result is not None:
+            out["rt_train"] = rt_result
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.batch)
         elif not args.no_cpu_baseline:

@@ -19,6 +19,8 @@ def main():
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if len(sys.argv) > 5 and sys.argv[5] == "rt":
+        return main_rt(rank, outfile)
     from transformerupscaler_amd.autograd import resize_aa
     from transformerupscaler_amd.dp import DataParallel
     from transformerupscaler_amd.weights import deterministic_state_dict
@@ -32,6 +34,38 @@ def main():
     out = resize_aa(model(lr, res_out=(54, 66), require_ratio=False), (54, 66))
     R = torch.rand((2, 3, 54, 66), generator=torch.Generator().manual_seed(5))[rank:rank + 1].cuda() - 0.5
     (out * R).sum().backward()
+    if rank == 0:
+        torch.save({k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}, outfile)
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"RANK{rank} OK", flush=True)
+
+
+def rt_small_model():
+    """ResidualTransformer plugin on a 4 x 6 token grid (64 x 96 input)."""
+    import torch.nn as nn
+    from transformerupscaler_amd.weights import rt_deterministic_state_dict
+    sd = rt_deterministic_state_dict(0)
+    sd["pos_embed"] = sd["pos_embed"][:, :24].clone()
+    m = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
+    m.pos_embed = nn.Parameter(torch.empty(1, 24, 128))
+    m.num_tokens = 24
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+def rt_inputs():
+    g = torch.Generator().manual_seed(11)
+    return torch.rand((2, 3, 64, 96), generator=g), torch.rand((2, 3, 96, 144), generator=g) - 0.5
+
+
+def main_rt(rank, outfile):
+    from transformerupscaler_amd.dp import DataParallel
+    model = rt_small_model()
+    DataParallel(model, bucket_mb=1.0)            # scale=None: every parameter is active
+    x, R = rt_inputs()
+    out = model(x[rank:rank + 1].cuda(), res_out=(96, 144))
+    (out * R[rank:rank + 1].cuda()).sum().backward()
     if rank == 0:
         torch.save({k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}, outfile)
     dist.barrier()

@@ -53,6 +53,32 @@ def main():
         print(tag, tuple(y.shape), float(y.mean()), float((y == 0).float().mean()), float((y == 1).float().mean()))
     for h in hs:
         h.remove()
+    make_train_fixture(model)
+
+
+def make_train_fixture(model):
+    """One training-graph evaluation (train.py:124-138 with dropout off = eval graph): L1 against a seeded HR target,
+    backward through the reference module; per parameter: gradient norm / abs-max, 64 sampled entries, and the
+    full gradient of the small parameters."""
+    g = torch.Generator().manual_seed(4321)
+    lr = torch.rand((1, 3, 720, 1280), generator=g)
+    hr = torch.rand((1, 3, 1080, 1920), generator=g)
+    model.zero_grad()
+    out = model(lr, res_out=(1080, 1920))
+    loss = torch.nn.functional.l1_loss(out, hr)
+    loss.backward()
+    d = {"loss": np.float64(loss.item())}
+    gi = torch.Generator().manual_seed(99)
+    for k, p in model.named_parameters():
+        gr = p.grad.detach().double().flatten()
+        idx = torch.randint(0, gr.numel(), (64,), generator=gi)
+        d["gstat_" + k] = np.array([gr.mean().item(), gr.norm().item(), gr.abs().max().item()])
+        d["gidx_" + k] = idx.numpy()
+        d["gval_" + k] = gr[idx].float().numpy()
+        if gr.numel() <= 4096:
+            d["gfull_" + k] = p.grad.detach().float().numpy()
+    np.savez_compressed(os.path.join(HERE, "rt_train_1080p.npz"), **d)
+    print("train fixture: loss", loss.item(), "params", len(list(model.named_parameters())))
 
 
 if __name__ == "__main__":

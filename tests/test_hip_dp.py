@@ -43,3 +43,22 @@ def test_two_rank_dp_grads_equal_single_process(det_sd, golden_dir, tmp_path):
         worst = max(worst, rel)
         assert rel <= 2e-2, f"{k}: {rel:.4f}"
     print("worst relative L2 between DP(2 ranks) and single process:", worst)
+
+
+def test_two_rank_dp_residual_transformer(tmp_path):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _dp_gpu_worker as W
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    outfile = str(tmp_path / "dp_rt_grads.pt")
+    procs = [subprocess.Popen([sys.executable, W.__file__, str(r), "2", port, outfile, "rt"], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    dp = torch.load(outfile)
+    model = W.rt_small_model()
+    x, R = W.rt_inputs()
+    (model(x.cuda(), res_out=(96, 144)) * R.cuda()).sum().backward()
+    for k, p in model.named_parameters():
+        ref, got = p.grad.cpu().double() / 2, dp[k].double()
+        rel = (got - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        assert rel <= 2e-2, f"{k}: {rel:.4f}"

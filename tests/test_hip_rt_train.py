@@ -114,3 +114,33 @@ def test_train_mode_dropout_step():
     assert torch.equal(out2.detach(), out.detach())
     for p in model.parameters():
         assert p.grad is None or torch.isfinite(p.grad).all()
+
+
+def test_full_size_train_grads_match_reference_fixture(golden_dir):
+    """720x1280 -> 1080x1920, L1 loss, eval graph: every parameter gradient against the fixture generated from the
+    real reference module (tests/golden/make_golden_rt.py).  L1's sign cotangent: tolerance as in test_hip_train.py."""
+    import os
+    d = dict(np.load(os.path.join(golden_dir, "rt_train_1080p.npz")))
+    m = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
+    m.load_state_dict(rt_deterministic_state_dict(0))
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(4321)
+    lr = torch.rand((1, 3, 720, 1280), generator=g).cuda()
+    hr = torch.rand((1, 3, 1080, 1920), generator=g).cuda()
+    loss = F.l1_loss(m(lr, res_out=(1080, 1920)), hr)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 2e-3
+    worst_s = worst_n = 0.0
+    for k, p in m.named_parameters():
+        st = d["gstat_" + k]
+        gr = p.grad.detach().double().cpu().flatten()
+        e_s = np.abs(gr[torch.from_numpy(d["gidx_" + k])].float().numpy() - d["gval_" + k]).max() / max(st[2], 1e-12)
+        e_n = abs(gr.norm().item() - st[1]) / max(st[1], 1e-12)
+        worst_s, worst_n = max(worst_s, e_s), max(worst_n, e_n)
+        if "gfull_" + k in d:
+            full = torch.from_numpy(d["gfull_" + k]).double().flatten()
+            rel = (gr - full).norm().item() / max(full.norm().item(), 1e-12)
+            assert rel <= 0.10, f"{k}: relative L2 error {rel:.4f}"
+        assert e_s <= 0.10, f"{k}: sampled max err {e_s:.4f} of max|g|"
+        assert e_n <= 0.05, f"{k}: norm err {e_n:.4f}"
+    print("worst sampled", worst_s, "worst norm", worst_n)

@@ -71,3 +71,20 @@ def test_bicubic_taps_match_aten():
         assert (ref - mine).abs().max().item() <= 2e-5
         idx2, w2 = R.bicubic_taps(i, o)
         assert (idx == idx2).all() and np.abs(w - w2).max() == 0
+
+
+def test_rt_oracle_backward_matches_reference_fixture(golden_dir, rt_sd):
+    """Autograd through the oracle == autograd through the reference module (fixture rt_train_1080p.npz)."""
+    d = dict(np.load(os.path.join(golden_dir, "rt_train_1080p.npz")))
+    g = torch.Generator().manual_seed(4321)
+    lr = torch.rand((1, 3, 720, 1280), generator=g)
+    hr = torch.rand((1, 3, 1080, 1920), generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in rt_sd.items()}
+    loss = F.l1_loss(R.forward(leaf, lr, res_out=(1080, 1920)), hr)
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 1e-6
+    for k, v in leaf.items():
+        gr = v.grad.double().flatten()
+        st = d["gstat_" + k]
+        assert abs(gr.norm().item() - st[1]) <= 2e-3 * st[1] + 1e-12, k
+        assert np.abs(gr[torch.from_numpy(d["gidx_" + k])].float().numpy() - d["gval_" + k]).max() <= 2e-3 * st[2] + 1e-9, k

@@ -18,12 +18,12 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
     uint32_t thresh, float inv_keep, uint32_t seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t vlds[4][64 * HD];
+    __shared__ __attribute__((aligned(16))) float comb_o[4][4][64][4];     // [wave][qt][lane][e] partial outputs
+    __shared__ float comb_m[4][4][16], comb_l[4][4][16];                   // [wave][qt][query column]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
-    int wid = blockIdx.x * 4 + wave;
-    const int total = B * RH * qtiles;
-    const bool active = wid < total;
-    if (!active) wid = total - 1;
+    // one workgroup per (image, head, 64-query tile); its 4 waves split the key tiles and merge at the end
+    const int wid = blockIdx.x;
     const int qt0 = wid % qtiles;
     const int h = (wid / qtiles) % RH;
     const int b = wid / (qtiles * RH);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
     for (int t = 0; t < 4; ++t) { oacc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; mrun[t] = -INFINITY; lrun[t] = 0.f; }
 
     const int ktiles = (N + 63) / 64;
-    for (int kt0 = 0; kt0 < ktiles; ++kt0) {
+    for (int kt0 = wave; kt0 < ktiles; kt0 += 4) {
         const int k0 = kt0 * 64;
         // stage V tile [64 keys][16] for the transposed fragments (wave-private region)
         {
@@ -116,15 +116,40 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (!active) return;
+    // merge the four key splits: common max, rescale, then wave w finishes query sub-tile w
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+        if (g == 0) comb_m[wave][qt][p] = mrun[qt];
+    __syncthreads();
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
+        const float M = fmaxf(fmaxf(comb_m[0][qt][p], comb_m[1][qt][p]), fmaxf(comb_m[2][qt][p], comb_m[3][qt][p]));
+        const float sc = __expf(mrun[qt] - M);             // 0 for a wave that saw no key tile
+        f32x4 o = oacc[qt];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] *= sc;
+        *reinterpret_cast<f32x4*>(&comb_o[wave][qt][lane][0]) = o;
+        if (g == 0) comb_l[wave][qt][p] = lrun[qt] * sc;
+    }
+    __syncthreads();
+    {
+        const int qt = wave;
         const int q = q0 + 16 * qt + p;
-        if (q >= N) continue;
-        const float inv = 1.0f / lrun[qt];
-        if (lse && g == 0) lse[((size_t)b * RH + h) * N + q] = mrun[qt] + __logf(lrun[qt]);     // saved for the backward
+        if (q >= N) return;
+        f32x4 o = *reinterpret_cast<const f32x4*>(&comb_o[0][qt][lane][0]);
+        float l = comb_l[0][qt][p];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&comb_o[w][qt][lane][0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += t[e];
+            l += comb_l[w][qt][p];
+        }
+        const float M = fmaxf(fmaxf(comb_m[0][qt][p], comb_m[1][qt][p]), fmaxf(comb_m[2][qt][p], comb_m[3][qt][p]));
+        const float inv = 1.0f / l;
+        if (lse && g == 0) lse[((size_t)b * RH + h) * N + q] = M + __logf(l);     // saved for the backward
         bf16_t* op = out + ((size_t)b * N + q) * RD + h * HD + 4 * g;
-        *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(oacc[qt][0] * inv, oacc[qt][1] * inv), pack_bf16x2(oacc[qt][2] * inv, oacc[qt][3] * inv)};
+        *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv)};
     }
 }
 
@@ -245,12 +270,10 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
     uint32_t thresh, float inv_keep, uint32_t seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t klds[4][64 * HD];
+    __shared__ __attribute__((aligned(16))) float red[4][4][64][4];          // [wave][qt][lane][e]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
-    int wid = blockIdx.x * 4 + wave;
-    const int total = B * RH * tiles;
-    const bool active = wid < total;
-    if (!active) wid = total - 1;
+    const int wid = blockIdx.x;                    // (image, head, query tile); the waves split the key tiles
     const int qt0 = wid % tiles, h = (wid / tiles) % RH, b = wid / (tiles * RH);
     const bf16_t* base = qkv + (size_t)b * N * (3 * RD) + h * HD;
     const bf16_t* gbase = go + (size_t)b * N * RD + h * HD;
@@ -269,7 +292,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
     f32x4 dq[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) dq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt0 = 0; kt0 < tiles; ++kt0) {
+    for (int kt0 = wave; kt0 < tiles; kt0 += 4) {
         const int k0 = kt0 * 64;
         {
             const int row = min(k0 + lane, N - 1);
@@ -312,13 +335,22 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
             }
         wave_sync_lds();
     }
-    if (!active) return;
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < 4; ++qt) *reinterpret_cast<f32x4*>(&red[wave][qt][lane][0]) = dq[qt];
+    __syncthreads();
+    {
+        const int qt = wave;
         const int q = q0 + 16 * qt + p;
-        if (q >= N) continue;
+        if (q >= N) return;
+        f32x4 o = *reinterpret_cast<const f32x4*>(&red[0][qt][lane][0]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&red[w][qt][lane][0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += t[e];
+        }
         bf16_t* op = gqkv + ((size_t)b * N + q) * (3 * RD) + h * HD + 4 * g;
-        *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(dq[qt][0] * 0.25f, dq[qt][1] * 0.25f), pack_bf16x2(dq[qt][2] * 0.25f, dq[qt][3] * 0.25f)};
+        *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(o[0] * 0.25f, o[1] * 0.25f), pack_bf16x2(o[2] * 0.25f, o[3] * 0.25f)};
     }
 }
 
@@ -329,12 +361,10 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
     uint32_t thresh, float inv_keep, uint32_t seed)
 {
     __shared__ __attribute__((aligned(16))) bf16_t lds[4][2][64 * HD];          // per wave: Q tile, dO tile
+    __shared__ __attribute__((aligned(16))) float red[4][8][64][4];             // [wave][dV kt | dK kt][lane][e]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
-    int wid = blockIdx.x * 4 + wave;
-    const int total = B * RH * tiles;
-    const bool active = wid < total;
-    if (!active) wid = total - 1;
+    const int wid = blockIdx.x;                    // (image, head, key tile); the waves split the query tiles
     const int kt0 = wid % tiles, h = (wid / tiles) % RH, b = wid / (tiles * RH);
     const bf16_t* base = qkv + (size_t)b * N * (3 * RD) + h * HD;
     const bf16_t* gbase = go + (size_t)b * N * RD + h * HD;
@@ -354,7 +384,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
     for (int t = 0; t < 4; ++t) { dvT[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dkT[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     bf16_t* ql = lds[wave][0];
     bf16_t* dol = lds[wave][1];
-    for (int qt0 = 0; qt0 < tiles; ++qt0) {
+    for (int qt0 = wave; qt0 < tiles; qt0 += 4) {
         const int q0 = qt0 * 64;
         {
             const int row = min(q0 + lane, N - 1);
@@ -413,14 +443,28 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
             }
         wave_sync_lds();
     }
-    if (!active) return;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
+        *reinterpret_cast<f32x4*>(&red[wave][kt][lane][0]) = dvT[kt];
+        *reinterpret_cast<f32x4*>(&red[wave][4 + kt][lane][0]) = dkT[kt];
+    }
+    __syncthreads();
+    {
+        const int kt = wave;
         const int key = k0 + 16 * kt + p;
-        if (key >= N) continue;
+        if (key >= N) return;
+        f32x4 dv = *reinterpret_cast<const f32x4*>(&red[0][kt][lane][0]);
+        f32x4 dk = *reinterpret_cast<const f32x4*>(&red[0][4 + kt][lane][0]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&red[w][kt][lane][0]);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(&red[w][4 + kt][lane][0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dv[e] += a[e]; dk[e] += c[e]; }
+        }
         bf16_t* op = gqkv + ((size_t)b * N + key) * (3 * RD) + h * HD + 4 * g;
-        *reinterpret_cast<u32x2*>(op + RD) = u32x2{pack_bf16x2(dkT[kt][0] * 0.25f, dkT[kt][1] * 0.25f), pack_bf16x2(dkT[kt][2] * 0.25f, dkT[kt][3] * 0.25f)};
-        *reinterpret_cast<u32x2*>(op + 2 * RD) = u32x2{pack_bf16x2(dvT[kt][0], dvT[kt][1]), pack_bf16x2(dvT[kt][2], dvT[kt][3])};
+        *reinterpret_cast<u32x2*>(op + RD) = u32x2{pack_bf16x2(dk[0] * 0.25f, dk[1] * 0.25f), pack_bf16x2(dk[2] * 0.25f, dk[3] * 0.25f)};
+        *reinterpret_cast<u32x2*>(op + 2 * RD) = u32x2{pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3])};
     }
 }
 
@@ -472,8 +516,9 @@ extern "C" int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int 
     const float inv_keep = 1.0f / (1.0f - drop_p);
     if (B <= 0 || N <= 0) return 0;
     const int qtiles = (N + 63) / 64;
-    const long long waves = (long long)B * RH * qtiles;
-    const dim3 grid((unsigned)((waves + 3) / 4));
+    const long long blocks = (long long)B * RH * qtiles;
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
     if (drop_p > 0.f)
         rt_attention_kernel<true><<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
             (const bf16_t*)qkv, (bf16_t*)out, lse, B, N, qtiles, thresh, inv_keep, drop_seed);
@@ -524,8 +569,9 @@ extern "C" int tup_rt_attention_bwd(const void* qkv, const void* out, const void
     rt_attn_bwd_prep_kernel<<<dim3((unsigned)((nprep + 255) / 256)), dim3(256), 0, s>>>((const bf16_t*)out, (const bf16_t*)gout, work, B, N);
     TUP_CHECK_LAUNCH();
     const int tiles = (N + 63) / 64;
-    const long long waves = (long long)B * RH * tiles;
-    const unsigned grid = (unsigned)((waves + 3) / 4);
+    const long long blocks = (long long)B * RH * tiles;
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const unsigned grid = (unsigned)blocks;
     if (drop_p > 0.f) {
         rt_attn_bwd_dq_kernel<true><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)qkv, (const bf16_t*)gout, lse, work, (bf16_t*)gqkv, B, N, tiles, thresh, inv_keep, drop_seed);
         TUP_CHECK_LAUNCH();

@@ -22,10 +22,13 @@ from .weights import active_param_names, param_shapes
 
 
 class GradReducer:
-    def __init__(self, scale: int, device, process_group=None, bucket_mb: float = 6.0, names: Optional[List[str]] = None):
+    def __init__(self, scale: Optional[int], device, process_group=None, bucket_mb: float = 6.0, names: Optional[List[str]] = None,
+                 shapes: Optional[Dict[str, tuple]] = None):
+        """scale: FastTransformer training scale (selects the active parameter set); pass scale=None with explicit
+        `names` + `shapes` for a model whose parameters are all active (ResidualTransformer)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        shapes = param_shapes()
+        shapes = dict(shapes) if shapes is not None else param_shapes()
         self.names = list(names) if names is not None else active_param_names(scale)
         self.shapes = {n: shapes[n] for n in self.names}
         self.numel = {n: int(torch.Size(self.shapes[n]).numel()) for n in self.names}
@@ -100,10 +103,14 @@ class DataParallel:
 
     Parameters are broadcast from rank 0 at construction so every replica starts identical."""
 
-    def __init__(self, module, scale: int, process_group=None, bucket_mb: float = 6.0):
+    def __init__(self, module, scale: Optional[int] = None, process_group=None, bucket_mb: float = 6.0):
         self.module = module
         dev = next(module.parameters()).device
-        self.reducer = GradReducer(scale, dev, process_group, bucket_mb)
+        if scale is None:        # every parameter is active (ResidualTransformer): take names / shapes from the module
+            named = {n: tuple(p.shape) for n, p in module.named_parameters() if p.requires_grad}
+            self.reducer = GradReducer(None, dev, process_group, bucket_mb, names=list(named), shapes=named)
+        else:
+            self.reducer = GradReducer(scale, dev, process_group, bucket_mb)
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
             for p in module.parameters():
                 dist.broadcast(p.data, src=0, group=process_group)

@@ -261,6 +261,16 @@ int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga, float* tm
                        const float* yw, const int* xstart, const int* xo, const float* xw, int planes, int Ha, int Wa,
                        int Ho, int Wo, void* stream);
 
+/* ---- frame pre/post-processing either side of the model ---- */
+
+/* torchvision ToTensor on a uint8 frame (reference data_handling/data_class.py:61-71, inference.py:65-75,
+ * app_overlay.py preproc): src u8 [B][H][W][3] -> dst fp32 [B][3][H][W] = src / 255.  swap_rb = 1: BGR source. */
+int tup_u8hwc_to_f32chw(const void* src, float* dst, int B, int H, int W, int swap_rb, void* stream);
+
+/* (x * 255).clamp(0, 255).to(uint8).permute(1, 2, 0)[..., [2, 1, 0]] (reference app_overlay.py:381-388; ToPILImage
+ * in inference.py:123-124): src fp32 [B][3][H][W] -> dst u8 [B][H][W][3], truncating.  swap_rb = 1: BGR output. */
+int tup_f32chw_to_u8hwc(const float* src, void* dst, int B, int H, int W, int swap_rb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

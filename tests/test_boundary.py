@@ -62,6 +62,29 @@ def test_checkpoint_roundtrip_and_latest(tmp_path, det_sd):
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
 
 
+def test_harness_checkpoint_resume_with_optimizer(tmp_path, det_sd):
+    """harness.save_checkpoint / load_latest_checkpoint: reference-format weight file + Adam sidecar."""
+    from transformerupscaler_amd import harness
+    mod = importlib.import_module("models.FastTransformer.model")
+    m = mod.TransformerModel()
+    m.load_state_dict(det_sd, strict=False)
+    opt = harness.make_optimizer(m)
+    p = m.conv1.weight
+    p.grad = torch.ones_like(p)
+    opt.step()
+    path = harness.save_checkpoint(m, str(tmp_path), 3, optimizer=opt)
+    assert path.endswith("model_epoch_3.pth")
+    plain = torch.load(path, map_location="cpu")
+    assert list(plain.keys()) == list(m.state_dict().keys())               # what the reference's load_state_dict expects
+    m2 = mod.TransformerModel()
+    opt2 = harness.make_optimizer(m2)
+    assert harness.load_latest_checkpoint(m2, str(tmp_path), optimizer=opt2, map_location="cpu") == 3
+    assert torch.equal(m2.conv1.weight, m.conv1.weight)
+    st = opt2.state_dict()["state"]
+    assert len(st) == 1 and float(next(iter(st.values()))["step"]) == 1.0
+    assert harness.load_latest_checkpoint(m2, str(tmp_path / "missing")) == 0
+
+
 def _emulate_conv_c64(x_nhwc, wp, bp, r):
     """What conv3x3_c64_kernel<4,0> computes from the packed operands (fp32 emulation)."""
     from transformerupscaler_amd.packing import _PERM64

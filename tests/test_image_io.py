@@ -1,0 +1,75 @@
+"""Frame pre/post-processing: the numpy oracle against the reference's torch expressions (CPU),
+and the HIP kernels against the oracle, bit-exact (GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import image_io_oracle as IO
+
+
+def frames(shape, seed):
+    return torch.randint(0, 256, shape, dtype=torch.uint8, generator=torch.Generator().manual_seed(seed))
+
+
+def outputs(shape, seed):
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(seed)) * 1.2 - 0.1        # some values outside [0, 1]
+    x.view(-1)[:8] = torch.tensor([0.0, 1.0, 0.5, 1.0 / 255, 254.999 / 255, 2.0, -1.0, 0.999999])
+    return x
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 7, 3), (2, 16, 12, 3)])
+def test_oracle_matches_reference_expressions(shape):
+    f = frames(shape, 1)
+    ref = f.permute(0, 3, 1, 2).contiguous().float().div(255)                    # ToTensor
+    assert np.array_equal(IO.to_tensor(f.numpy()), ref.numpy())
+    x = outputs((shape[0], 3, shape[1], shape[2]), 2)
+    up = (x * 255).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)             # app_overlay.py:381-384
+    assert np.array_equal(IO.to_frame(x.numpy()), up.numpy())
+    assert np.array_equal(IO.to_frame(x.numpy(), bgr=True), up[..., [2, 1, 0]].numpy())      # :386
+    assert np.array_equal(IO.to_frame(IO.to_tensor(f.numpy())), f.numpy())                   # byte round trip is the identity
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 5, 7, 3), (2, 16, 12, 3), (1, 720, 1280, 3), (3, 33, 31, 3)])
+@pytest.mark.parametrize("bgr", [False, True])
+def test_hip_frame_conversions_bit_exact(shape, bgr):
+    from transformerupscaler_amd import ops
+    f = frames(shape, 3)
+    got = ops.frames_to_tensor(f.cuda(), bgr=bgr).cpu().numpy()
+    assert np.array_equal(got, IO.to_tensor(f.numpy(), bgr=bgr))
+    x = outputs((shape[0], 3, shape[1], shape[2]), 4)
+    got = ops.tensor_to_frames(x.cuda(), bgr=bgr).cpu().numpy()
+    assert np.array_equal(got, IO.to_frame(x.numpy(), bgr=bgr))
+    # u8 -> float -> u8 round trip is the identity for every byte value
+    allb = torch.arange(256, dtype=torch.uint8).repeat(3).view(1, 16, 16, 3).contiguous()
+    rt = ops.tensor_to_frames(ops.frames_to_tensor(allb.cuda(), bgr=bgr), bgr=bgr).cpu()
+    assert torch.equal(rt, allb)
+
+
+@pytest.mark.gpu
+def test_frame_path_under_hipgraph_replay_equals_eager():
+    """uint8 frame -> model -> uint8 frame captured into a hipGraph (speed_test.py --graph, the live-overlay path,
+    reference app_overlay.py:337-420) replays to exactly the eager result, also for a new frame in the static buffer."""
+    import importlib
+    from transformerupscaler_amd import ops
+    from transformerupscaler_amd.weights import deterministic_state_dict
+    m = importlib.import_module("models.FastTransformer.model").TransformerModel()
+    m.load_state_dict(deterministic_state_dict(0), strict=False)
+    m = m.cuda().eval()
+    f0, f1 = frames((90, 120, 3), 5).cuda(), frames((90, 120, 3), 6).cuda()
+
+    def one(frame):
+        return ops.tensor_to_frames(m(ops.frames_to_tensor(frame, bgr=True), res_out=(270, 360)), bgr=True)
+
+    with torch.no_grad():
+        eager0, eager1 = one(f0).clone(), one(f1).clone()
+        torch.cuda.synchronize()
+        static_in = f0.clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = one(static_in)
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(static_out, eager0)
+        static_in.copy_(f1)
+        g.replay(); torch.cuda.synchronize()
+        assert torch.equal(static_out, eager1)

@@ -28,9 +28,28 @@ def train_step(model, optimizer, lr_batch: torch.Tensor, hr_batch: torch.Tensor)
     return loss.detach()
 
 
-def save_checkpoint(model, checkpoint_dir: str, epoch: int) -> str:
-    """train.py:152-156: weights only, ``model_epoch_{n}.pth``."""
+def save_checkpoint(model, checkpoint_dir: str, epoch: int, optimizer=None) -> str:
+    """train.py:152-156: weights only, ``model_epoch_{n}.pth`` -- the file the reference's drivers load
+    (``model.load_state_dict(torch.load(path))``, train.py:90, inference.py:97, speed_test.py:45), in both directions.
+    The reference drops the optimizer state; with `optimizer` it goes to a sidecar ``optim_epoch_{n}.pt`` so a resumed
+    run continues Adam's moments without changing the weight file's format."""
     os.makedirs(checkpoint_dir, exist_ok=True)
     path = os.path.join(checkpoint_dir, f"model_epoch_{epoch}.pth")
-    torch.save(model.state_dict(), path)
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+    if optimizer is not None:
+        torch.save(optimizer.state_dict(), os.path.join(checkpoint_dir, f"optim_epoch_{epoch}.pt"))
     return path
+
+
+def load_latest_checkpoint(model, checkpoint_dir: str, optimizer=None, map_location=None) -> int:
+    """Resume as train.py:86-92 does (latest ``*_<epoch>.pth``, strict load); returns the epoch (0 if none)."""
+    from tools.utils import get_latest_checkpoint
+    try:
+        path, epoch = get_latest_checkpoint(checkpoint_dir)
+    except (FileNotFoundError, OSError):
+        return 0
+    model.load_state_dict(torch.load(path, map_location=map_location))
+    side = os.path.join(checkpoint_dir, f"optim_epoch_{epoch}.pt")
+    if optimizer is not None and os.path.exists(side):
+        optimizer.load_state_dict(torch.load(side, map_location=map_location))
+    return epoch

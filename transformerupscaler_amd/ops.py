@@ -578,3 +578,24 @@ def rt_bicubic_sum(a, b, size, clamp=True):
               ayi.data_ptr(), ayw.data_ptr(), axi.data_ptr(), axw.data_ptr(), byi.data_ptr(), byw.data_ptr(),
               bxi.data_ptr(), bxw.data_ptr(), B * C, Ha, Wa, Hb, Wb, Ho, Wo, int(clamp), _stream())
     return out
+
+
+# ---- frame pre/post-processing ----
+def frames_to_tensor(frames_u8, bgr=False):
+    """uint8 [B][H][W][3] (or [H][W][3]) on the GPU -> fp32 [B][3][H][W] in [0, 1] (ToTensor); bgr=True for BGR frames."""
+    if frames_u8.dim() == 3:
+        frames_u8 = frames_u8.unsqueeze(0)
+    B, H, W, C = frames_u8.shape
+    assert C == 3
+    out = torch.empty((B, 3, H, W), dtype=F32, device=frames_u8.device)
+    _lib.call("tup_u8hwc_to_f32chw", _chk(frames_u8, torch.uint8, None, "frames"), out.data_ptr(), B, H, W, int(bgr), _stream())
+    return out
+
+
+def tensor_to_frames(x, bgr=False):
+    """fp32 [B][3][H][W] -> uint8 [B][H][W][3] = trunc(clamp(x * 255, 0, 255)); bgr=True writes BGR (app_overlay.py:381-388)."""
+    B, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=x.device)
+    _lib.call("tup_f32chw_to_u8hwc", _chk(x, F32, None, "x"), out.data_ptr(), B, H, W, int(bgr), _stream())
+    return out

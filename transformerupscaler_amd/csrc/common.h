@@ -78,6 +78,33 @@ TUP_DEVICE f32x2 fast_erf2(f32x2 z) {
 }
 TUP_DEVICE float fast_erf(float z) { return fast_erf2(f32x2{z, z})[0]; }
 
+// GELU of N value pairs with the N polynomial chains advanced in lockstep (step-major order): a dependent
+// v_pk_fma_f32 needs its predecessor's result, so one chain at a time leaves the VALU waiting (hipcc pads it with
+// s_nop); N independent chains fill those slots.  Same arithmetic as gelu_erf2 below, value for value.
+template <int N>
+TUP_DEVICE void gelu_erf2_batch(f32x2 (&x)[N]) {
+    f32x2 zc[N], w[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const f32x2 z = x[i] * 0.70710678118654752440f;
+        zc[i][0] = fminf(fmaxf(z[0], -2.9f), 2.9f);
+        zc[i][1] = fminf(fmaxf(z[1], -2.9f), 2.9f);
+        w[i] = zc[i] * zc[i];
+        q[i] = w[i] * -5.423542948079785e-09f + 2.6428506316733547e-07f;
+    }
+    constexpr float C[8] = {-5.823991614306578e-06f, 7.786024070810527e-05f, -0.000718351046089083f, 0.004940473474562168f,
+                            -0.026508823037147522f, 0.11259414255619049f, -0.37605419754981995f, 1.1283738613128662f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) q[i] = q[i] * w[i] + C[k];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const f32x2 hx = x[i] * 0.5f;
+        x[i] = hx * (zc[i] * q[i]) + hx;
+    }
+}
+
 // nn.GELU() default = exact erf form (reference model.py:148)
 TUP_DEVICE f32x2 gelu_erf2(f32x2 x) {
     const f32x2 hx = x * 0.5f;

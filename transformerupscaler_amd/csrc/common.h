@@ -32,6 +32,21 @@ TUP_DEVICE bf16x8 lds_read_b128_asm(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// Same with the instruction's 16-bit immediate offset: unrolled loops then share a few base registers instead of
+// one VGPR per (loop-invariant, hence hoisted) address.  `off` must fold to a constant < 65536.
+TUP_DEVICE bf16x8 lds_read_b128_asm_off(uint32_t addr, int off) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(off));
+    return v;
+}
+// ... and with "^ 64" (the kh = 1 half of a 128-B row) applied inside the asm, so that the flipped address is a
+// 1-instruction temporary instead of a second hoisted register per table entry.
+TUP_DEVICE bf16x8 lds_read_b128_asm_off_x64(uint32_t addr, int off) {
+    bf16x8 v;
+    uint32_t tmp;
+    asm volatile("v_xor_b32 %1, 64, %2\n\tds_read_b128 %0, %1 offset:%3" : "=v"(v), "=&v"(tmp) : "v"(addr), "i"(off));
+    return v;
+}
 template <int N> TUP_DEVICE void lds_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 TUP_DEVICE float bf16_to_f32(bf16_t v) { return static_cast<float>(v); }

@@ -236,13 +236,17 @@ __device__ __attribute__((aligned(16))) unsigned int tup_zero_line[4] = {0u, 0u,
 // Store sink for lanes whose pixel is outside the image: keeps the number of store instructions per wave
 // fixed (the counted vmcnt below relies on it); never read.
 __device__ __attribute__((aligned(16))) unsigned int tup_store_sink[64 * 8];
+// Timing experiments (TUP_CONV_STAMPS=1, scripts/_conv_stamps.py): s_memtime of wave 0 of each group of workgroup 100
+// at the phase boundaries of the first phases.  [group][phase][0 = phase start, 1 = K loop end | DMA issued,
+// 2 = stores issued, 3 = vmcnt wait over, 4 = barrier passed]
+__device__ unsigned long long tup_conv_stamps[2][16][5];
 
 template <int CT, int OUT_MODE, int KS>
 __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ add, const bf16_t* __restrict__ mask,
     void* __restrict__ out, int B, int H, int W, int ntiles, int r, int cout_valid, int relu,
-    int tilesX, int tilesY)
+    int tilesX, int tilesY, int stamps)
 {
     constexpr int PADK = KS / 2, HALO_W = TW + KS - 1, HALO_H = TH + KS - 1, NPIX_HALO = HALO_H * HALO_W;
     constexpr int NTAPS = KS * KS;
@@ -258,6 +262,21 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     const int total_tiles = tilesX * tilesY * B;
     char* my_in = in_lds + grp * IN_BYTES;
 
+    // Halo-image DMA.  The (pixel, chunk) -> source-offset map of a lane's pieces does not depend on the tile, so it
+    // is computed once (rel[]); an interior tile then costs one 64-bit add + one DMA per piece.  (The issuing group
+    // shares its SIMDs with the other group's MFMA stream and gets roughly one VALU issue per 12-18 cycles: the
+    // ~30 address instructions per piece of the general path made DMA issue 4.1 k cycles of a 12.5 k-cycle phase.)
+    constexpr int NPIECE = (IN_CHUNKS + 255) / 256;
+    int rel[NPIECE];
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
+        const int idx = min(it * 256 + tid, IN_CHUNKS - 1);
+        const int q = idx >> 3, c = (idx & 7) ^ ((q >> 1) & 7);
+        const int yy = q / HALO_W, xx = q - yy * HALO_W;
+        rel[it] = ((yy - PADK) * W + (xx - PADK)) * 128 + c * 16;
+    }
+    constexpr bool LAST_PARTIAL = (IN_CHUNKS % 256) != 0;
+    const bool last_ok = (NPIECE - 1) * 256 + tid < IN_CHUNKS;
     auto prefetch_tile = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
@@ -265,6 +284,16 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
         const char* xb = reinterpret_cast<const char*>(x + (size_t)b * H * W * 64);
+        if (ty0 >= PADK && ty0 + TH + PADK <= H && tx0 >= PADK && tx0 + TW + PADK <= W) {       // interior tile
+            const char* tb = xb + ((size_t)ty0 * W + tx0) * 128;
+#pragma unroll
+            for (int it = 0; it < NPIECE; ++it) {
+                if (LAST_PARTIAL && it == NPIECE - 1 && !last_ok) continue;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + rel[it]),
+                                                 (__attribute__((address_space(3))) void*)(my_in + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll 1
         for (int base = 0; base < IN_CHUNKS; base += 256) {
             const int idx = base + tid;                     // physical 16-B chunk of the LDS image
@@ -289,36 +318,59 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     };
 
     // loop-invariant LDS byte offsets of this lane's fragments (kh = 0; kh = 1 is "^ 64")
-    uint32_t poff[NTAPS][4];
+    // Fragment addresses = a few base registers + the ds_read immediate offset.  Pixel group pg = 2*row + half: the
+    // second half of a row is 16 pixels = 2048 B further and has the same swizzle phase ((q >> 1) & 7 is unchanged by
+    // q + 16), so the table holds the two rows of each tap (with this group's image base folded in; the image is
+    // 128-B aligned, so the kh = 1 form is still "^ 64").  Weights: row p of slab (tap, ct) = wbase + a constant.
+    uint32_t poff[NTAPS][2];
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap)
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg)
-            poff[tap][pg] = (uint32_t)swz128((2 * wave + (pg >> 1)) * HALO_W + (pg & 1) * 16 + p + (tap / KS) * HALO_W + (tap % KS), g);
-    const uint32_t wbase = lds_addr(w_lds) + (uint32_t)swz128(p, g);
-    const uint32_t ibase = lds_addr(my_in);
+        for (int rw = 0; rw < 2; ++rw)
+            poff[tap][rw] = lds_addr(my_in) + (uint32_t)swz128((2 * wave + rw) * HALO_W + p + (tap / KS) * HALO_W + (tap % KS), g);
+    const uint32_t wbase0 = lds_addr(w_lds) + (uint32_t)swz128(p, g), wbase1 = wbase0 ^ 64u;
+    const uint32_t wbase0h = wbase0 + 57344u, wbase1h = wbase1 + 57344u;          // second window of the 16-bit offset
 
     f32x4 acc[4][CT];
+    // this lane's bias values live in LDS ([g][ct][4] floats after the two input images), not in 4*CT registers
+    float* bias_lds = reinterpret_cast<float*>(in_lds + 2 * IN_BYTES);
+    const uint32_t bias_addr = lds_addr(bias_lds) + (uint32_t)(g * CT * 16);
+    // K loop: fragments are requested TWO K-steps ahead (3-slot ring).  With the other group's DMA landing in LDS and
+    // its epilogue on the same SIMDs a ds_read_b128 takes ~500 cycles (stamped); one step (16 MFMAs = 256 cycles)
+    // of distance left the loop waiting on LDS: 10.4 k cycles per tile instead of the 4.6 k its MFMAs need.
     auto compute_tile = [&]() {
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg)
+        for (int ct = 0; ct < CT; ++ct) acc[0][ct] = __builtin_bit_cast(f32x4, lds_read_b128_asm(bias_addr + ct * 16));
+        lds_wait<0>();
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pg = 1; pg < 4; ++pg)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = acc[0][ct];      // bias rides in the accumulator
         constexpr int NSTEPS = NTAPS * 2;
-        bf16x8 pf[2][4], wf[2][CT];
+        constexpr int PER = 4 + CT;                                         // ds_reads per K-step
+        constexpr int W1 = PER * 2 > 15 ? 15 : PER * 2;                     // lgkmcnt is a 4-bit field
+        bf16x8 pf[3][4], wf[3][CT];
         auto load_frags = [&](int step, int slot) {
             const int tap = step >> 1;
-            const uint32_t khx = (step & 1) << 6;
 #pragma unroll
-            for (int pg = 0; pg < 4; ++pg) pf[slot][pg] = lds_read_b128_asm(ibase + (poff[tap][pg] ^ khx));
+            for (int pg = 0; pg < 4; ++pg)
+                pf[slot][pg] = (step & 1) ? lds_read_b128_asm_off_x64(poff[tap][pg >> 1], (pg & 1) * 2048)
+                                          : lds_read_b128_asm_off(poff[tap][pg >> 1], (pg & 1) * 2048);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) wf[slot][ct] = lds_read_b128_asm((wbase ^ khx) + (tap * WROWS + ct * 16) * 128);
+            for (int ct = 0; ct < CT; ++ct) {
+                const int woff = (tap * WROWS + ct * 16) * 128;
+                wf[slot][ct] = woff < 57344 ? lds_read_b128_asm_off((step & 1) ? wbase1 : wbase0, woff)
+                                            : lds_read_b128_asm_off((step & 1) ? wbase1h : wbase0h, woff - 57344);
+            }
         };
         load_frags(0, 0);
+        load_frags(1, 1);
 #pragma unroll
         for (int step = 0; step < NSTEPS; ++step) {
-            const int cur = step & 1;
-            if (step + 1 < NSTEPS) { load_frags(step + 1, cur ^ 1); lds_wait<4 + CT>(); } else { lds_wait<0>(); }
+            const int cur = step % 3;
+            if (step + 2 < NSTEPS) { load_frags(step + 2, (step + 2) % 3); lds_wait<W1>(); }
+            else if (step + 1 < NSTEPS) { lds_wait<PER>(); }
+            else { lds_wait<0>(); }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pg = 0; pg < 4; ++pg)
@@ -328,7 +380,6 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         }
     };
 
-    f32x4 bv[CT];
     auto store_tile = [&](int tile, int nt) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
@@ -354,12 +405,27 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
                 }
+                if (!add && !mask) {
+                    // common case: ReLU on the packed bf16 pairs as a signed-16-bit max with 0 (negative bf16 = negative
+                    // int16), one v_pk_max_i16 per two values instead of one v_max_f32 per value
+                    typedef short s16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        pk[ct * 2 + 0] = pack_bf16x2(acc[pg][ct][0], acc[pg][ct][1]);
+                        pk[ct * 2 + 1] = pack_bf16x2(acc[pg][ct][2], acc[pg][ct][3]);
+                    }
+                    if (relu) {
+#pragma unroll
+                        for (int q = 0; q < 2 * CT; ++q)
+                            pk[q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[q]), s16x2{0, 0}));
+                    }
+                } else
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[pg][ct][e] + bv[ct][e];
+                        v[e] = acc[pg][ct][e];                     // bias already in the accumulator
                         if (relu) v[e] = fmaxf(v[e], 0.f);
                         const int wi = (ct * 4 + e) >> 1;
                         if (add && ok) v[e] += __builtin_bit_cast(float, (e & 1) ? (aw[wi] & 0xffff0000u) : (aw[wi] << 16));
@@ -387,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                     for (int e = 0; e < 4; ++e) {
                         const int co = 16 * ct + 4 * g + e;
                         if (co < cout_valid) {
-                            float v = acc[pg][ct][e] + bv[ct][e];
+                            float v = acc[pg][ct][e];
                             if (relu) v = fmaxf(v, 0.f);
                             const int c = co / rr, sp = co - c * rr;
                             const int si = sp / r, sj = sp - si * r;
@@ -407,26 +473,28 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
 
     for (int nt = 0; nt < ntiles; ++nt) {
         stage_weights(nt);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {            // bias of this lane's output channels, once per cout tile
-            bv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (threadIdx.x < 16 * CT) {                 // bias of this cout tile in the order the lanes read it: [g][ct][e]
+            const int gg = threadIdx.x / (4 * CT), ct = (threadIdx.x / 4) % CT, e = threadIdx.x & 3;
+            float bval = 0.f;
             if (bias) {
-                if constexpr (OUT_MODE == OUT_NHWC_BF16) bv[ct] = *reinterpret_cast<const f32x4*>(bias + nt * 64 + g * 16 + ct * 4);
-                else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const int co = 16 * ct + 4 * g + e; bv[ct][e] = co < cout_valid ? bias[co] : 0.f; }
-                }
+                if constexpr (OUT_MODE == OUT_NHWC_BF16) bval = bias[nt * 64 + gg * 16 + ct * 4 + e];
+                else { const int co = 16 * ct + 4 * gg + e; bval = co < cout_valid ? bias[co] : 0.f; }
             }
+            bias_lds[threadIdx.x] = bval;
         }
         if (grp == 0 && my_count > 0) prefetch_tile(first);
         __syncthreads();            // weights + group 0's first tile visible (the barrier's vmcnt(0) retires the DMA)
 
         // phase ph: group (ph & 1) runs the K loop of its tile k = ph >> 1; the other group stores its previous
         // tile and DMA-fetches its next one into its (now idle) buffer.  One workgroup barrier per phase.
+        const bool st_on = stamps && blockIdx.x == 100 && (threadIdx.x & 255) == 0 && nt == 0;
+        auto stamp = [&](int ph, int i) { if (st_on && ph < 16) tup_conv_stamps[grp][ph][i] = __builtin_amdgcn_s_memtime(); };
         for (int ph = 0; ph < nphases; ++ph) {
             const int k = ph >> 1;
+            stamp(ph, 0);
             if ((ph & 1) == grp) {
                 if (k < my_count) compute_tile();
+                stamp(ph, 1);
             } else {
                 // group 0 is here on odd phases (just computed tile k, next is k+1); group 1 on even phases
                 // (computed tile k-1 in phase ph-1, next is k)
@@ -435,8 +503,10 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 // DMA first: it then has the whole phase (the other group's K loop) to land; the buffer is idle
                 // because this group's own K loop ended before the last barrier
                 if (nxt < my_count) prefetch_tile(first + nxt * stride);
+                stamp(ph, 1);
                 if (done >= 0 && done < my_count) {
                     store_tile(first + done * stride, nt);
+                    stamp(ph, 2);
                     // The DMA (issued first) must have landed before the barrier; the 8 stores issued after it need
                     // not: vmcnt counts in issue order, so "all but the youngest 8" = the DMA.  (A __syncthreads()
                     // here makes hipcc wait vmcnt(0), i.e. for the stores' write latency, which was the longest
@@ -448,7 +518,9 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(ph, 3);
             __builtin_amdgcn_s_barrier();
+            stamp(ph, 4);
         }
         // drain before the next pass restages the weights / the kernel ends
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -461,7 +533,7 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
                       int B, int H, int W, int ntiles, int r, int cout_valid, int relu, hipStream_t s)
 {
     constexpr int NPIX_HALO = (TH + KS - 1) * (TW + KS - 1);
-    constexpr size_t lds = (size_t)KS * KS * CT * 16 * 128 + 2 * (size_t)NPIX_HALO * 128;
+    constexpr size_t lds = (size_t)KS * KS * CT * 16 * 128 + 2 * (size_t)NPIX_HALO * 128 + 256;     // + bias
     static_assert(lds <= 163840, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
@@ -474,9 +546,10 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
+    static const int conv_stamps_on = getenv("TUP_CONV_STAMPS") ? 1 : 0;
     conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(512), lds, s>>>(
         (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, B, H, W, ntiles, r,
-        cout_valid, relu, tilesX, tilesY);
+        cout_valid, relu, tilesX, tilesY, conv_stamps_on);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -619,4 +692,10 @@ extern "C" int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const f
         (const bf16_t*)x, (const bf16_t*)wv, bv, out, B, H, W, r, relu);
     TUP_CHECK_LAUNCH();
     return 0;
+}
+
+// Timing experiments only: the s_memtime stamps of the last launch under TUP_CONV_STAMPS=1 (2 groups x 16 phases x 5).
+extern "C" int tup_debug_conv_stamps(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_conv_stamps), sizeof(unsigned long long) * 2 * 16 * 5);
 }

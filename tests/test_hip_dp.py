@@ -14,15 +14,31 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def run_two_workers(worker, outfile, extra=()):
+    """Two ranks sharing cuda:0 over gloo.  The rendezvous port is picked by binding port 0 and releasing it, which can
+    race with another process on a busy box: one retry on a fresh port if the workers do not finish in time."""
+    last = None
+    for attempt in range(2):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+        procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, outfile, *extra], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        try:
+            outs = [p.communicate(timeout=150)[0] for p in procs]
+        except subprocess.TimeoutExpired:
+            for p in procs:
+                p.kill()
+            last = [p.communicate()[0] for p in procs]
+            continue
+        assert all(p.returncode == 0 for p in procs), outs
+        return outs
+    pytest.fail(f"DP workers did not finish in two attempts: {last}")
+
+
 def test_two_rank_dp_grads_equal_single_process(det_sd, golden_dir, tmp_path):
     from transformerupscaler_amd.autograd import resize_aa
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_gpu_worker.py")
     outfile = str(tmp_path / "dp_grads.pt")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, outfile], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    run_two_workers(worker, outfile)
     dp = torch.load(outfile)
 
     d = dict(np.load(os.path.join(golden_dir, "train_g36x44.npz")))
@@ -48,12 +64,8 @@ def test_two_rank_dp_grads_equal_single_process(det_sd, golden_dir, tmp_path):
 def test_two_rank_dp_residual_transformer(tmp_path):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import _dp_gpu_worker as W
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
     outfile = str(tmp_path / "dp_rt_grads.pt")
-    procs = [subprocess.Popen([sys.executable, W.__file__, str(r), "2", port, outfile, "rt"], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), outs
+    run_two_workers(W.__file__, outfile, extra=("rt",))
     dp = torch.load(outfile)
     model = W.rt_small_model()
     x, R = W.rt_inputs()

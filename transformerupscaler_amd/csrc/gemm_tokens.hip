@@ -164,6 +164,91 @@ TUP_DEVICE void gemm_store_row(const GemmParams& p, int m, int n0, int g, const 
     }
 }
 
+// The same epilogues split in two for the panel kernel: the operands an epilogue READS (residual row, skip pixels,
+// saved pre-activation) are requested before the K loop of the tile and consumed after it, so their HBM round trip
+// hides under the MFMAs instead of being paid between the K loop and the stores of every 64-column tile.
+struct EpiPre {
+    u32x4 a[4];
+    size_t off;          // E_UNEMBED: element offset of this lane's 16 channels
+    bool ok;
+};
+
+template <int EPI>
+TUP_DEVICE EpiPre epi_prefetch(const GemmParams& p, int m, int n0, int g)
+{
+    EpiPre r;
+    r.ok = true; r.off = 0;
+    const int nb = n0 + g * 16;
+    if constexpr (EPI == E_RES_F32) {
+        const float* rs = p.res + (size_t)m * p.ldo + nb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r.a[q] = *reinterpret_cast<const u32x4*>(rs + 4 * q);
+    } else if constexpr (EPI == E_GELU_BWD) {
+        const bf16_t* pr = p.skip + (size_t)m * p.ldo + nb;
+        r.a[0] = *reinterpret_cast<const u32x4*>(pr); r.a[1] = *reinterpret_cast<const u32x4*>(pr + 8);
+    } else if constexpr (EPI == E_UNEMBED) {
+        const TokPos t = token_of_row(m, p);
+        const int pix = n0 >> 6, i = pix >> 3, j = pix & 7;
+        const int py = t.ty * 8 + i, px = t.tx * 8 + j;
+        r.ok = t.valid && py < p.H && px < p.W;
+        r.off = (((size_t)t.b * p.H + py) * p.W + px) * 64 + g * 16;
+        r.a[0] = u32x4{0u, 0u, 0u, 0u}; r.a[1] = u32x4{0u, 0u, 0u, 0u};
+        if (p.skip && r.ok) {
+            r.a[0] = *reinterpret_cast<const u32x4*>(p.skip + r.off);
+            r.a[1] = *reinterpret_cast<const u32x4*>(p.skip + r.off + 8);
+        }
+    }
+    return r;
+}
+
+template <int EPI>
+TUP_DEVICE void epi_finish(const GemmParams& p, int m, int n0, int g, const float (&v)[16], const float (&bvec)[16], const EpiPre& pre)
+{
+    const int nb = n0 + g * 16;
+    if constexpr (EPI == E_RES_F32) {
+        float* o = (float*)p.out + (size_t)m * p.ldo + nb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 rv = __builtin_bit_cast(f32x4, pre.a[q]);
+            f32x4 ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = v[4 * q + e] + bvec[4 * q + e];
+                if (p.drop_thresh)
+                    t *= drop_scale(p.drop_seed, (uint32_t)m * (uint32_t)p.ldo + nb + 4 * q + e, p.drop_thresh, p.drop_inv_keep);
+                ov[e] = t + rv[e];
+            }
+            *reinterpret_cast<f32x4*>(o + 4 * q) = ov;
+        }
+    } else if constexpr (EPI == E_GELU_BWD) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t sw = (q < 4) ? pre.a[0][q & 3] : pre.a[1][q & 3];
+            const float xa = __builtin_bit_cast(float, sw << 16), xb = __builtin_bit_cast(float, sw & 0xffff0000u);
+            pk[q] = pack_bf16x2(v[2 * q] * gelu_erf_grad(xa), v[2 * q + 1] * gelu_erf_grad(xb));
+        }
+        bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + nb;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    } else if constexpr (EPI == E_UNEMBED) {
+        if (!pre.ok) return;
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t sw = (q < 4) ? pre.a[0][q & 3] : pre.a[1][q & 3];
+            const float sa = __builtin_bit_cast(float, sw << 16);
+            const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
+            pk[q] = pack_bf16x2(v[2 * q] + bvec[2 * q] + sa, v[2 * q + 1] + bvec[2 * q + 1] + sb);
+        }
+        bf16_t* o = (bf16_t*)p.out + pre.off;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    } else {
+        gemm_store_row<EPI>(p, m, n0, g, v, bvec);          // nothing to read ahead
+    }
+}
+
 TUP_DEVICE void gemm_load_bias(const GemmParams& p, int n0, int g, bool unembed, float (&bvec)[16])
 {
     const int bb = unembed ? g * 16 : n0 + g * 16;
@@ -420,6 +505,14 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const GemmParams p)
         store_w();
         __syncthreads();                        // W tile nt (and, first time, the A tile) visible
         if (nt + 1 < ntiles) load_w(nt + 1);
+        // epilogue operands of THIS tile: requested now, consumed after the K loop
+        const int n0 = nt * 64;
+        float bvec[16];
+        gemm_load_bias(p, n0, g, EPI == E_UNEMBED, bvec);
+        EpiPre pre[2];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) pre[tg] = epi_prefetch<EPI>(p, min(m0 + 32 * wave + 16 * tg + pl, p.M - 1), n0, g);
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[2][4];
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg)
@@ -449,9 +542,6 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const GemmParams p)
             }
         }
         __syncthreads();                        // everyone done reading W tile nt
-        const int n0 = nt * 64;
-        float bvec[16];
-        gemm_load_bias(p, n0, g, EPI == E_UNEMBED, bvec);
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) {
             const int m = m0 + 32 * wave + 16 * tg + pl;
@@ -461,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const GemmParams p)
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ct][e];
-            gemm_store_row<EPI>(p, m, n0, g, v, bvec);
+            epi_finish<EPI>(p, m, n0, g, v, bvec, pre[tg]);
         }
     }
 }

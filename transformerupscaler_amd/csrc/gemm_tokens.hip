@@ -519,20 +519,31 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const GemmParams p)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
-            bf16x8 tf[2][2], wf[2][4];
+            // fragments two K-steps ahead (3-slot ring), addresses = 3 base registers + immediate offsets: one step is
+            // 8 MFMAs = 128 cycles, the LDS round trip under load is several hundred (stamped in the conv kernel)
+            bf16x8 tf[3][2], wf[3][4];
             auto ld = [&](int step, int slot) {
                 const int kc = step >> 1;
-                const uint32_t khx = (step & 1) << 6;
-                tf[slot][0] = lds_read_b128_asm((a_tok0 ^ khx) + kc * (PBM * 128));
-                tf[slot][1] = lds_read_b128_asm((a_tok1 ^ khx) + kc * (PBM * 128));
+                if (step & 1) {
+                    tf[slot][0] = lds_read_b128_asm_off_x64(a_tok0, kc * (PBM * 128));
+                    tf[slot][1] = lds_read_b128_asm_off_x64(a_tok1, kc * (PBM * 128));
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) wf[slot][ct] = lds_read_b128_asm((w_frag ^ khx) + kc * (64 * 128) + ct * 2048);
+                    for (int ct = 0; ct < 4; ++ct) wf[slot][ct] = lds_read_b128_asm_off_x64(w_frag, kc * (64 * 128) + ct * 2048);
+                } else {
+                    tf[slot][0] = lds_read_b128_asm_off(a_tok0, kc * (PBM * 128));
+                    tf[slot][1] = lds_read_b128_asm_off(a_tok1, kc * (PBM * 128));
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) wf[slot][ct] = lds_read_b128_asm_off(w_frag, kc * (64 * 128) + ct * 2048);
+                }
             };
             ld(0, 0);
+            ld(1, 1);
 #pragma unroll
             for (int step = 0; step < 6; ++step) {
-                const int cur = step & 1;
-                if (step + 1 < 6) { ld(step + 1, cur ^ 1); lds_wait<6>(); } else { lds_wait<0>(); }
+                const int cur = step % 3;
+                if (step + 2 < 6) { ld(step + 2, (step + 2) % 3); lds_wait<12>(); }
+                else if (step + 1 < 6) { lds_wait<6>(); }
+                else { lds_wait<0>(); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tg = 0; tg < 2; ++tg)

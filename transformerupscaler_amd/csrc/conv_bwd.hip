@@ -34,7 +34,7 @@ TUP_DEVICE void stage_x_halo(char* lds, const bf16_t* xb, int H, int W, int ty0,
 // whole 64 x 576 partial result lives in registers (144 per lane) and is flushed once.
 // G may be the sub-pixel plane `sp` of a pixel-shuffled gradient [B][H*gr][W*gr][64].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
+__global__ __launch_bounds__(512) void conv3x3_wgrad_c64_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ gmap, float* __restrict__ dwp, float* __restrict__ dbias,
     int B, int H, int W, int gr, int sp, int tilesX, int tilesY, int xr, int xsp)
 {
@@ -46,52 +46,102 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
     const int trq = l16 >> 2, trp = l16 & 3;
     const int si = sp / gr, sj = sp - si * gr;
     const int Hg = H * gr, Wg = W * gr;
+    const int cit = wave & 3, coh = wave >> 2;
 
-    f32x4 acc[9][4];
+    // Work split (8 waves): wave w owns the input-channel tile cit = w & 3, the cout pair coh = w >> 2 and all nine
+    // taps, so one K-step is 2 G fragments + 9 X fragments for 18 MFMAs.  (With "wave = cout tile" every wave re-read
+    // all 36 X fragments: 37 transposed reads per 36 MFMAs.)
+    f32x4 acc[9][2];                 // [tap][cout tile of the pair]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+        for (int c = 0; c < 2; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
 
-    const int ntiles = tilesX * tilesY * B;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Register double-buffering of the tile operands: the X halo (340 pixels x 8 chunks -> 6 pieces per thread) and
+    // the G tile (256 x 8 -> 4 pieces) of tile k+1 are requested before the K loop of tile k and written to LDS after
+    // it, so the global-load round trip hides under the MFMAs (it used to sit between the two barriers of every tile).
+    constexpr int XP = (NPIX_HALO * 8 + 511) / 512;
+    u32x4 xpre[XP], gpre[4];
+    const int xsi = xsp / xr, xsj = xsp % xr;
+    auto fetch_tile = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
         const int ty = t % tilesY;
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
-        stage_x_halo(x_lds, x + (size_t)b * H * W * 64 * xr * xr, H, W, ty0, tx0, tid, xr, xsp / xr, xsp % xr);
+        const bf16_t* xb = x + (size_t)b * H * W * 64 * xr * xr;
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int idx = tid + u * 512;
+            const int q = idx >> 3, c = idx & 7;
+            const int yy = q / HALO_W, xx = q - yy * HALO_W;
+            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+            xpre[u] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < NPIX_HALO * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                xpre[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)(iy * xr + xsi) * (W * xr) + (ix * xr + xsj)) * 64 + c * 8);
+        }
         const bf16_t* gb = gmap + (size_t)b * Hg * Wg * 64;
-        for (int idx = tid; idx < 256 * 8; idx += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + u * 512;
             const int pix = idx >> 3, c = idx & 7;
             const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
-            u32x4 v = {0u, 0u, 0u, 0u};
+            gpre[u] = u32x4{0u, 0u, 0u, 0u};
             if (oy < H && ox < W)
-                v = *reinterpret_cast<const u32x4*>(gb + ((size_t)(oy * gr + si) * Wg + (ox * gr + sj)) * 64 + c * 8);
-            *reinterpret_cast<u32x4*>(g_lds + swz128(pix, c)) = v;
+                gpre[u] = *reinterpret_cast<const u32x4*>(gb + ((size_t)(oy * gr + si) * Wg + (ox * gr + sj)) * 64 + c * 8);
         }
+    };
+    auto commit_tile = [&]() {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int idx = tid + u * 512;
+            if (idx < NPIX_HALO * 8) *reinterpret_cast<u32x4*>(x_lds + swz128(idx >> 3, idx & 7)) = xpre[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + u * 512;
+            *reinterpret_cast<u32x4*>(g_lds + swz128(idx >> 3, idx & 7)) = gpre[u];
+        }
+    };
+
+    const int ntiles = tilesX * tilesY * B;
+    if ((int)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        commit_tile();
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
+        // One K-step = one tile row of 32 pixels on v_mfma_f32_16x16x32_bf16 (the 16x16x16 form runs at half its
+        // rate on gfx950): lane group g contracts pixels 8g .. 8g+7, delivered by two transposed reads (4 pixels each).
+        auto join = [](s16x4 lo, s16x4 hi) {
+            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+            return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+        };
 #pragma unroll 1
-        for (int ks = 0; ks < 16; ++ks) {
-            const int ry = ks >> 1, x0 = (ks & 1) * 16;
-            const int gp = ry * 32 + x0 + 4 * g + trq;
-            const int gcol = 16 * wave + 4 * trp;
-            const s16x4 af = lds_read_tr16(g_lds + swz128(gp, gcol >> 3) + (gcol & 7) * 2);
-            {   // bias gradient: this lane holds G[4 pixels][co = 16*wave + l16]
-                const bf16x4 av = __builtin_bit_cast(bf16x4, af);
-                bsum += bf16_to_f32(av[0]) + bf16_to_f32(av[1]) + bf16_to_f32(av[2]) + bf16_to_f32(av[3]);
+        for (int ry = 0; ry < TH; ++ry) {
+            const int gp = ry * 32 + 8 * g + trq;
+            bf16x8 af[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int gcol = 16 * (2 * coh + c) + 4 * trp;
+                af[c] = join(lds_read_tr16(g_lds + swz128(gp, gcol >> 3) + (gcol & 7) * 2),
+                             lds_read_tr16(g_lds + swz128(gp + 4, gcol >> 3) + (gcol & 7) * 2));
             }
-            const int qbase = ry * HALO_W + x0 + 4 * g + trq;
+            if (cit == 0) {    // bias gradient: this lane holds G[8 pixels][co = 16*(2*coh + c) + l16]
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bsum[c] += bf16_to_f32(af[c][j]);
+            }
+            const int qbase = ry * HALO_W + 8 * g + trq;
+            const int xcol = 16 * cit + 4 * trp;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int q = qbase + (tap / 3) * HALO_W + (tap % 3);
+                const bf16x8 bfr = join(lds_read_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2),
+                                        lds_read_tr16(x_lds + swz128(q + 4, xcol >> 3) + (xcol & 7) * 2));
 #pragma unroll
-                for (int cit = 0; cit < 4; ++cit) {
-                    const int xcol = 16 * cit + 4 * trp;
-                    const s16x4 bfr = lds_read_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2);
-                    acc[tap][cit] = mfma16x16x16(af, bfr, acc[tap][cit]);
-                }
+                for (int c = 0; c < 2; ++c) acc[tap][c] = mfma16x16x32(af[c], bfr, acc[tap][c]);
             }
         }
         __syncthreads();
@@ -100,14 +150,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_c64_kernel(
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int cit = 0; cit < 4; ++cit)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                atomicAdd(dwp + ((size_t)(16 * wave + 4 * g + e) * 9 + tap) * 64 + 16 * cit + l16, acc[tap][cit][e]);
-    if (dbias) {
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        if (g == 0) atomicAdd(dbias + 16 * wave + l16, bsum);
+                atomicAdd(dwp + ((size_t)(16 * (2 * coh + c) + 4 * g + e) * 9 + tap) * 64 + 16 * cit + l16, acc[tap][c][e]);
+    if (dbias && cit == 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float v = bsum[c];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (g == 0) atomicAdd(dbias + 16 * (2 * coh + c) + l16, v);
+        }
     }
 }
 
@@ -485,7 +539,7 @@ static int conv_c64_wgrad_launch(const void* x, const void* gmap, float* dwp, fl
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, 2)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+    conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, 1)), dim3(512), lds, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)x, (const bf16_t*)gmap, dwp, dbias, B, H, W, gr, sp, tilesX, tilesY, xr, xsp);
     TUP_CHECK_LAUNCH();
     return 0;

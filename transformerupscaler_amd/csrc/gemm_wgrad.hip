@@ -126,16 +126,24 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
         if (s + 1 < nsteps) load_stage(s + 1);
         const char* pb = smem + buf * (2 * 64 * 128);
         const char* qb = pb + 64 * 128;
+        // two K-steps of 32 rows on v_mfma_f32_16x16x32_bf16 (the 16x16x16 form runs at half its rate on gfx950):
+        // lane group g contracts rows 8g .. 8g+7, delivered by two transposed reads of 4 rows each
+        auto join = [](s16x4 lo, s16x4 hi) {
+            const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+            return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+        };
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int row = 16 * ks + 4 * g + trq;
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = 32 * ks + 8 * g + trq;
             const int pcol = 16 * wave + 4 * trp;
-            const s16x4 af = lds_read_tr16(pb + swz128(row, pcol >> 3) + (pcol & 7) * 2);
+            const bf16x8 af = join(lds_read_tr16(pb + swz128(row, pcol >> 3) + (pcol & 7) * 2),
+                                   lds_read_tr16(pb + swz128(row + 4, pcol >> 3) + (pcol & 7) * 2));
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
                 const int qcol = 16 * jt + 4 * trp;
-                const s16x4 bfr = lds_read_tr16(qb + swz128(row, qcol >> 3) + (qcol & 7) * 2);
-                acc[jt] = mfma16x16x16(af, bfr, acc[jt]);
+                const bf16x8 bfr = join(lds_read_tr16(qb + swz128(row, qcol >> 3) + (qcol & 7) * 2),
+                                        lds_read_tr16(qb + swz128(row + 4, qcol >> 3) + (qcol & 7) * 2));
+                acc[jt] = mfma16x16x32(af, bfr, acc[jt]);
             }
         }
         if (s + 1 < nsteps) store_stage(buf ^ 1);

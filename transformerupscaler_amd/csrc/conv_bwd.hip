@@ -188,25 +188,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
         for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[3] = {0.f, 0.f, 0.f};
     for (int i = tid; i < 256 * 16; i += 256) g_lds[i] = f32_to_bf16(0.f);       // columns 3..15 stay zero
-    const int ntiles = tilesX * tilesY * B;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // register double-buffering of the tile operands (X halo: 11 pieces per thread, G: this thread's pixel): the loads
+    // of tile k+1 fly during the K loop of tile k -- this kernel is a 64-channel streaming read with little MFMA work
+    constexpr int XP = (NPIX_HALO * 8 + 255) / 256;
+    u32x4 xpre[XP];
+    float gpre[3];
+    auto fetch_tile = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
         const int ty = t % tilesY;
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
-        stage_x_halo(x_lds, x + (size_t)b * H * W * 64, H, W, ty0, tx0, tid);
-        {
-            const int oy = ty0 + (tid >> 5), ox = tx0 + (tid & 31);
-            const bool ok = oy < H && ox < W;
+        const bf16_t* xb = x + (size_t)b * H * W * 64;
 #pragma unroll
-            for (int co = 0; co < 3; ++co) {
-                const float v = ok ? gpl[(((size_t)b * 3 + co) * H + oy) * W + ox] : 0.f;
-                bsum[co] += v;
-                g_lds[tid * 16 + co] = f32_to_bf16(v);
-            }
+        for (int u = 0; u < XP; ++u) {
+            const int idx = tid + u * 256;
+            const int q = idx >> 3, c = idx & 7;
+            const int yy = q / HALO_W, xx = q - yy * HALO_W;
+            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+            xpre[u] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < NPIX_HALO * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                xpre[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * 64 + c * 8);
+        }
+        const int oy = ty0 + (tid >> 5), ox = tx0 + (tid & 31);
+        const bool ok = oy < H && ox < W;
+#pragma unroll
+        for (int co = 0; co < 3; ++co) gpre[co] = ok ? gpl[(((size_t)b * 3 + co) * H + oy) * W + ox] : 0.f;
+    };
+    const int ntiles = tilesX * tilesY * B;
+    if ((int)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int idx = tid + u * 256;
+            if (idx < NPIX_HALO * 8) *reinterpret_cast<u32x4*>(x_lds + swz128(idx >> 3, idx & 7)) = xpre[u];
+        }
+#pragma unroll
+        for (int co = 0; co < 3; ++co) {
+            bsum[co] += gpre[co];
+            g_lds[tid * 16 + co] = f32_to_bf16(gpre[co]);
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
 #pragma unroll 1
         for (int ks = 0; ks < 16; ++ks) {
             const int ry = ks >> 1, x0 = (ks & 1) * 16;

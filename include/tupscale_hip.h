@@ -271,6 +271,27 @@ int tup_u8hwc_to_f32chw(const void* src, float* dst, int B, int H, int W, int sw
  * in inference.py:123-124): src fp32 [B][3][H][W] -> dst u8 [B][H][W][3], truncating.  swap_rb = 1: BGR output. */
 int tup_f32chw_to_u8hwc(const float* src, void* dst, int B, int H, int W, int swap_rb, void* stream);
 
+/* ---- WindowTransformer plugin (models/WindowTransformer/model.py): the FastTransformer window
+ * block at embedding width 128 / 8 heads ---- */
+
+/* relative_position_bias_table [225][heads] -> dense S^T-fragment bias [heads*16*256] (heads = 8 or 12). */
+int tup_relpos_bias_expand_h(const float* table, float* frag, int heads, void* stream);
+
+/* WindowAttention core (model.py:125-143) for heads x 16 channels: qkv bf16 [nwin][64][48*heads] -> out bf16
+ * [nwin][64][16*heads]. */
+int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, void* out, int nwin, int heads, float drop_p,
+                          unsigned int drop_seed, void* stream);
+
+/* patch_embed (stride-8 conv, no padding: floor(H/8) x floor(W/8) tokens) + permute + zero token pad + window_partition
+ * (model.py:247-268): feat bf16 NHWC [B][H][W][64], Wt bf16 [N][4096], x_out fp32 window layout [B*nWy*nWx*64][N]. */
+int tup_wt_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, float* x_out, int B, int H, int W, int N,
+                           void* stream);
+
+/* window_reverse + crop + patch_unembed + cropped skip add (model.py:272-291): x fp32 window layout [M][K], Wt bf16
+ * [4096][K], skip / out bf16 NHWC [B][Hs][Ws][64] (Hs, Ws multiples of 8 = the token grid times 8). */
+int tup_wt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip, void* out,
+                             int B, int Hs, int Ws, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

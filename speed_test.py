@@ -66,7 +66,8 @@ def main():
         weights = f"{path} (epoch {epoch})"
     else:
         from transformerupscaler_amd import weights as W
-        sd = W.rt_deterministic_state_dict(0) if args.model == "ResidualTransformer" else W.deterministic_state_dict(0)
+        sd = {"ResidualTransformer": W.rt_deterministic_state_dict, "WindowTransformer": W.wt_deterministic_state_dict}.get(
+            args.model, W.deterministic_state_dict)(0)
         model.load_state_dict(sd, strict=False)
     model.eval()
     frames, source = load_frames(args, device)

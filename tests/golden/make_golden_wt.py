@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Golden fixtures for the WindowTransformer path from the REAL reference module
+(/root/reference/models/WindowTransformer/model.py; runs only in the build container)."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+
+
+def main():
+    sys.path.insert(0, ROOT)
+    from transformerupscaler_amd.weights import wt_deterministic_state_dict
+    sys.path.remove(ROOT)
+    for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        del sys.modules[k]
+    sys.path.insert(0, "/root/reference")
+    ref = importlib.import_module("models.WindowTransformer.model")
+    assert ref.__file__.startswith("/root/reference"), ref.__file__
+    sys.path.pop(0)
+    torch.set_num_threads(8)
+    model = ref.TransformerModel().eval()
+    res = model.load_state_dict(wt_deterministic_state_dict(0), strict=False)
+    assert not res.unexpected_keys and all(k.endswith("relative_position_index") for k in res.missing_keys), res
+    # (1) small geometries with every intermediate that matters: token pad (5x7 tokens -> 8x8) and the cropped skip
+    #     (H_d = 44 -> 5 token rows = 40 map rows), whole outputs stored
+    for tag, shape, kw in (("g88x120_x2", (1, 3, 88, 120), dict(upscale_factor=2)),
+                           ("g128x128_res", (2, 3, 128, 128), dict(res_out=(200, 168)))):
+        x = torch.rand(shape, generator=torch.Generator().manual_seed(2024))
+        caps = {}
+        hs = [model.window_blocks[0].register_forward_hook(lambda m, i, o: caps.__setitem__("block0", o.detach().clone())),
+              model.decoder_conv2.register_forward_hook(lambda m, i, o: caps.__setitem__("residual", o.detach().clone()))]
+        with torch.no_grad():
+            y = model(x, **kw)
+        for h in hs:
+            h.remove()
+        np.savez_compressed(os.path.join(HERE, f"wt_fwd_{tag}.npz"), x=x.numpy(), out=y.numpy().astype(np.float16),
+                            out_f32_patch=y[0, :, :24, :24].numpy(), residual=caps["residual"].numpy(),
+                            block0_head=caps["block0"][:2].numpy())
+        print(tag, tuple(y.shape), float(y.mean()), float((y == 0).float().mean()), float((y == 1).float().mean()))
+    # (2) 720p -> 1080p: statistics and patches
+    x = torch.rand((1, 3, 720, 1280), generator=torch.Generator().manual_seed(1234))
+    with torch.no_grad():
+        y = model(x, res_out=(1080, 1920))
+    gi = torch.Generator().manual_seed(77)
+    ys = torch.randint(0, 1080 - 32, (16,), generator=gi); xs = torch.randint(0, 1920 - 32, (16,), generator=gi)
+    np.savez_compressed(os.path.join(HERE, "wt_fwd_1080p.npz"), ys=ys.numpy(), xs=xs.numpy(),
+                        patches=np.stack([y[0, :, a:a + 32, b:b + 32].numpy() for a, b in zip(ys.tolist(), xs.tolist())]),
+                        stats=np.array([y.double().mean().item(), y.double().norm().item(), (y == 0).double().mean().item(),
+                                        (y == 1).double().mean().item()]),
+                        row_means=y[0].double().mean(dim=(0, 2)).float().numpy())
+    print("1080p", float(y.mean()))
+
+
+if __name__ == "__main__":
+    main()

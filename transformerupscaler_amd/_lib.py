@@ -46,6 +46,10 @@ SIGNATURES = {
     "tup_rt_patch_wgrad": [P, P, P, I, I, I, P],
     "tup_conv3x3_c64_wgrad_s2d": [P, P, P, P, I, I, I, I, I, P],
     "tup_rt_bicubic_bwd": [P] * 10 + [I, I, I, I, I, P],
+    "tup_relpos_bias_expand_h": [P, P, I, P],
+    "tup_window_attn_fwd_h": [P, P, P, I, I, F, U, P],
+    "tup_wt_patch_embed_fwd": [P, P, P, P, I, I, I, I, P],
+    "tup_wt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, I, P],
     "tup_u8hwc_to_f32chw": [P, P, I, I, I, I, P],
     "tup_f32chw_to_u8hwc": [P, P, I, I, I, I, P],
     "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],

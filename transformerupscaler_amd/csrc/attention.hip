@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int DIM = 192, HEADS = 12, HD = 16, NTOK = 64;
+constexpr int DIM = 192, HD = 16, NTOK = 64;
 
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
 
 // bias_frag[h][kt][qt][lane][e] = table[index(query, key)][h], query = 16qt + (lane&15),
 // key = 16kt + 4(lane>>4) + e: the C/D fragment layout of the S^T tiles.
+template <int NH>
 __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __restrict__ frag)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;        // over 12*4*4*64*4
+    constexpr int HEADS = NH;
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // over NH*4*4*64*4
     if (idx >= HEADS * 16 * 256) return;
     const int e = idx & 3, lane = (idx >> 2) & 63, qt = (idx >> 8) & 3, kt = (idx >> 10) & 3, h = idx >> 12;
     const int qi = 16 * qt + (lane & 15), kj = 16 * kt + 4 * (lane >> 4) + e;
@@ -68,10 +70,12 @@ __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __r
     frag[idx] = table[rel * HEADS + h];
 }
 
+template <int NH>       // heads of 16: 12 (FastTransformer, dim 192) or 8 (WindowTransformer, dim 128)
 __global__ __launch_bounds__(256) void window_attn_kernel(
     const bf16_t* __restrict__ qkv, const float* __restrict__ bias_frag, bf16_t* __restrict__ out, int npairs,
     uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
+    constexpr int HEADS = NH, DIM = NH * HD;
     __shared__ __attribute__((aligned(16))) bf16_t vlds[4][NTOK * HD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
@@ -148,18 +152,28 @@ __global__ __launch_bounds__(256) void window_attn_kernel(
     for (int qt = 0; qt < 4; ++qt) {
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
+        for (int kp = 0; kp < 2; ++kp) {
             // normalise before the bf16 rounding of P (softmax output is what the reference multiplies by v);
-            // attn_drop (model.py:127): element index = (pair*64 + query)*64 + key
-            float pv[4];
+            // attn_drop (model.py:127): element index = (pair*64 + query)*64 + key.
+            // Two key tiles per v_mfma_f32_16x16x32_bf16 (twice the rate of the x16 form): k index 8g + j <-> key
+            // 4g + j of tile 2kp (j < 4) or of tile 2kp + 1 (j >= 4), the same map on both operands.
+            uint32_t pw[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pv[e] = st[kt][qt][e] * inv[qt];
-                if (drop_thresh)
-                    pv[e] *= drop_scale(drop_seed, ((uint32_t)pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g + e, drop_thresh, drop_inv_keep);
+            for (int hh = 0; hh < 2; ++hh) {
+                const int kt = 2 * kp + hh;
+                float pv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pv[e] = st[kt][qt][e] * inv[qt];
+                    if (drop_thresh)
+                        pv[e] *= drop_scale(drop_seed, ((uint32_t)pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g + e, drop_thresh, drop_inv_keep);
+                }
+                pw[2 * hh] = pack_bf16x2(pv[0], pv[1]);
+                pw[2 * hh + 1] = pack_bf16x2(pv[2], pv[3]);
             }
-            const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
-            o = mfma16x16x16(vf[kt], __builtin_bit_cast(s16x4, pp), o);
+            const u32x2 va = __builtin_bit_cast(u32x2, vf[2 * kp]), vb = __builtin_bit_cast(u32x2, vf[2 * kp + 1]);
+            o = mfma16x16x32(__builtin_bit_cast(bf16x8, u32x4{va[0], va[1], vb[0], vb[1]}),
+                             __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]}), o);
         }
         // O^T tile: rows = hd 4g+e, col = query p  ->  out[win][16qt+p][h*16 + 4g .. +3]
         if (active) {
@@ -185,7 +199,18 @@ extern "C" int tup_layernorm_fwd(const float* x, const float* gamma, const float
 // table: fp32 [225][12] (relative_position_bias_table); frag: fp32 [12*16*256] in S^T fragment order.
 extern "C" int tup_relpos_bias_expand(const float* table, float* frag, void* stream)
 {
-    relpos_expand_kernel<<<dim3(HEADS * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(table, frag);
+    relpos_expand_kernel<12><<<dim3(12 * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(table, frag);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Same for `heads` = 8 (WindowTransformer: table fp32 [225][8], frag fp32 [8*16*256]) or 12.
+extern "C" int tup_relpos_bias_expand_h(const float* table, float* frag, int heads, void* stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (heads == 12) relpos_expand_kernel<12><<<dim3(12 * 16), dim3(256), 0, s>>>(table, frag);
+    else if (heads == 8) relpos_expand_kernel<8><<<dim3(8 * 16), dim3(256), 0, s>>>(table, frag);
+    else return (int)hipErrorInvalidValue;
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -197,10 +222,30 @@ extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void
 {
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
-    const int npairs = nwin * HEADS;
+    const int npairs = nwin * 12;
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    window_attn_kernel<<<dim3((npairs + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    window_attn_kernel<12><<<dim3((npairs + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// Same kernel for `heads` x 16 channels (8: WindowTransformer, models/WindowTransformer/model.py:67-143): qkv bf16
+// [nwin][64][3*16*heads], out bf16 [nwin][64][16*heads].
+extern "C" int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, void* out, int nwin, int heads, float drop_p,
+                                     unsigned int drop_seed, void* stream)
+{
+    if (nwin <= 0) return 0;
+    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
+    const int npairs = nwin * heads;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    const dim3 grid((npairs + 3) / 4);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (heads == 12)
+        window_attn_kernel<12><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+    else if (heads == 8)
+        window_attn_kernel<8><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+    else return (int)hipErrorInvalidValue;
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -740,3 +740,33 @@ extern "C" int tup_rt_patch_unembed_fwd(const float* x, const void* Wt, const fl
     p.M = B * p.Ht * p.Wt_; p.N = 4096; p.K = 128;
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }
+
+// ---- WindowTransformer token entry / exit (window layout, embedding width N = 128 or 192) ----
+// patch_embed without reflect padding (models/WindowTransformer/model.py:247-264: a stride-8 conv drops the remainder
+// rows / columns, the token grid is then zero-padded to whole windows): feat bf16 NHWC [B][H][W][64], Wt bf16 [N][4096],
+// x_out fp32 [B*nWy*nWx*64][N] window layout, token grid floor(H/8) x floor(W/8).
+extern "C" int tup_wt_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, float* x_out,
+                                      int B, int H, int W, int N, void* stream)
+{
+    if (N % 64 || H < 8 || W < 8) return (int)hipErrorInvalidValue;
+    GemmParams p{};
+    p.H = H; p.W = W; p.Ht = H / 8; p.Wt_ = W / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8; p.reflect = 0;
+    p.A = feat; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = x_out; p.ldo = N;
+    p.M = B * p.nWy * p.nWx * 64; p.N = N; p.K = 4096;
+    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// window_reverse + crop + patch_unembed + skip (model.py:272-291): x fp32 window layout [M][K], Wt bf16 [4096][K],
+// skip / out bf16 NHWC [B][Ht*8][Wt*8][64] with Ht = Hs/8, Wt = Ws/8 given as the map size Hs x Ws (multiples of 8).
+extern "C" int tup_wt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip, void* out,
+                                        int B, int Hs, int Ws, int K, void* stream)
+{
+    if (K % 64 || Hs % 8 || Ws % 8) return (int)hipErrorInvalidValue;
+    GemmParams p{};
+    p.H = Hs; p.W = Ws; p.Ht = Hs / 8; p.Wt_ = Ws / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
+    p.A = x; p.lda = K; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = K;
+    return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}

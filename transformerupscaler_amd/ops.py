@@ -599,3 +599,41 @@ def tensor_to_frames(x, bgr=False):
     out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=x.device)
     _lib.call("tup_f32chw_to_u8hwc", _chk(x, F32, None, "x"), out.data_ptr(), B, H, W, int(bgr), _stream())
     return out
+
+
+# ---- WindowTransformer: window block at width 128 / 8 heads ----
+def relpos_bias_expand_h(table, heads):
+    frag = torch.empty((heads, 4, 4, 64, 4), dtype=F32, device=table.device)
+    _lib.call("tup_relpos_bias_expand_h", _chk(table, F32, (225, heads), "table"), frag.data_ptr(), heads, _stream())
+    return frag
+
+
+def window_attn_h(qkv, bias_frag, heads, drop_p=0.0, drop_seed=0):
+    M, D = qkv.shape
+    assert D == 48 * heads and M % 64 == 0
+    out = torch.empty((M, 16 * heads), dtype=BF16, device=qkv.device)
+    _lib.call("tup_window_attn_fwd_h", _chk(qkv, BF16, None, "qkv"), _chk(bias_frag, F32, (heads, 4, 4, 64, 4), "bias"),
+              out.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+    return out
+
+
+def wt_patch_embed(feat, wt, bias):
+    """Stride-8 patch conv without padding (floor(H/8) x floor(W/8) tokens) -> fp32 window-layout tokens [M][N]."""
+    B, H, W, C = feat.shape
+    N = wt.shape[0]
+    nwy, nwx = (H // 8 + 7) // 8, (W // 8 + 7) // 8
+    x = torch.empty((B * nwy * nwx * 64, N), dtype=F32, device=feat.device)
+    _lib.call("tup_wt_patch_embed_fwd", _chk(feat, BF16, None, "feat"), _chk(wt, BF16, (N, 4096), "wt"), _chk(bias, F32, (N,), "bias"),
+              x.data_ptr(), B, H, W, N, _stream())
+    return x
+
+
+def wt_patch_unembed(x, wt, bias, skip):
+    """skip + ConvTranspose(k8, s8)(window_reverse(x)): skip / result NHWC bf16 [B][Ht*8][Wt*8][64]."""
+    B, Hs, Ws, C = skip.shape
+    K = wt.shape[1]
+    nwy, nwx = (Hs // 8 + 7) // 8, (Ws // 8 + 7) // 8
+    out = torch.empty_like(skip)
+    _lib.call("tup_wt_patch_unembed_fwd", _chk(x, F32, (B * nwy * nwx * 64, K), "x"), _chk(wt, BF16, (4096, K), "wt"),
+              _chk(bias, F32, (64,), "bias"), _chk(skip, BF16, None, "skip"), out.data_ptr(), B, Hs, Ws, K, _stream())
+    return out

@@ -283,3 +283,31 @@ def pack_rt_state_dict(sd: Dict[str, torch.Tensor], backward: bool = False) -> D
         for nm, key in (("in", "attn.in_proj_weight"), ("out", "attn.out_proj.weight"), ("fc1", "mlp.0.weight"), ("fc2", "mlp.2.weight")):
             pk[f"b{i}.{nm}.wd"] = pack_linear(t(f"{p}.{key}").t().contiguous())
     return pk
+
+
+# ------------------------------------------------------------------------------------------------
+# WindowTransformer
+# ------------------------------------------------------------------------------------------------
+def pack_wt_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    pk: Dict[str, torch.Tensor] = {}
+    f32 = lambda t: t.detach().float().contiguous()
+    t = lambda k: sd[k].detach()
+    dim = sd["patch_embed.weight"].shape[0]
+    pk["conv1.w"] = pack_conv1(t("conv1.weight")); pk["conv1.b"] = f32(sd["conv1.bias"])
+    pk["conv2.w"], pk["conv2.b"] = pack_conv_c64(t("conv2.weight"), t("conv2.bias"), 1)
+    pk["ds.w"], pk["ds.b"] = pack_conv_c64_stride2(t("downsample.weight"), t("downsample.bias"))
+    pk["pe.w"] = pack_linear(t("patch_embed.weight").permute(0, 2, 3, 1).reshape(dim, 4096)); pk["pe.b"] = f32(sd["patch_embed.bias"])
+    nb = 0
+    while f"window_blocks.{nb}.norm1.weight" in sd:
+        p = f"window_blocks.{nb}"
+        for nm in ("norm1", "norm2"):
+            pk[f"b{nb}.{nm}.w"] = f32(sd[f"{p}.{nm}.weight"]); pk[f"b{nb}.{nm}.b"] = f32(sd[f"{p}.{nm}.bias"])
+        pk[f"b{nb}.table"] = f32(sd[f"{p}.attn.relative_position_bias_table"])
+        for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
+            pk[f"b{nb}.{nm}.w"] = pack_linear(t(f"{p}.{key}.weight")); pk[f"b{nb}.{nm}.b"] = f32(sd[f"{p}.{key}.bias"])
+        nb += 1
+    pk["nblocks"] = nb
+    pk["pu.w"] = pack_linear(t("patch_unembed.weight").permute(2, 3, 1, 0).reshape(4096, dim)); pk["pu.b"] = f32(sd["patch_unembed.bias"])
+    pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(t("decoder_conv1.weight"), t("decoder_conv1.bias"), 1)
+    pk["dec2.w"] = pack_conv_c64_thin(t("decoder_conv2.weight")); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])
+    return pk

@@ -157,3 +157,54 @@ def rt_deterministic_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str,
             t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(_fan_in(name, shape))
         sd[name] = t.to(dtype)
     return sd
+
+
+# ------------------------------------------------------------------------------------------------
+# WindowTransformer plugin (reference models/WindowTransformer/model.py:172-225): state_dict layout
+# ------------------------------------------------------------------------------------------------
+WT_DIM, WT_HEADS, WT_BLOCKS, WT_MLP = 128, 8, 8, 512
+
+
+def wt_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["conv1.weight"] = (BASE, IN_CH, 3, 3); s["conv1.bias"] = (BASE,)
+    s["conv2.weight"] = (BASE, BASE, 3, 3); s["conv2.bias"] = (BASE,)
+    s["downsample.weight"] = (BASE, BASE, 3, 3); s["downsample.bias"] = (BASE,)
+    s["patch_embed.weight"] = (WT_DIM, BASE, 8, 8); s["patch_embed.bias"] = (WT_DIM,)
+    for i in range(WT_BLOCKS):
+        p = f"window_blocks.{i}"
+        s[p + ".norm1.weight"] = (WT_DIM,); s[p + ".norm1.bias"] = (WT_DIM,)
+        s[p + ".attn.relative_position_bias_table"] = (225, WT_HEADS)
+        s[p + ".attn.qkv.weight"] = (3 * WT_DIM, WT_DIM); s[p + ".attn.qkv.bias"] = (3 * WT_DIM,)
+        s[p + ".attn.proj.weight"] = (WT_DIM, WT_DIM); s[p + ".attn.proj.bias"] = (WT_DIM,)
+        s[p + ".norm2.weight"] = (WT_DIM,); s[p + ".norm2.bias"] = (WT_DIM,)
+        s[p + ".mlp.0.weight"] = (WT_MLP, WT_DIM); s[p + ".mlp.0.bias"] = (WT_MLP,)
+        s[p + ".mlp.2.weight"] = (WT_DIM, WT_MLP); s[p + ".mlp.2.bias"] = (WT_DIM,)
+    s["patch_unembed.weight"] = (WT_DIM, BASE, 8, 8); s["patch_unembed.bias"] = (BASE,)
+    s["decoder_conv1.weight"] = (BASE, BASE, 3, 3); s["decoder_conv1.bias"] = (BASE,)
+    s["decoder_conv2.weight"] = (IN_CH, BASE, 3, 3); s["decoder_conv2.bias"] = (IN_CH,)
+    return s
+
+
+def wt_deterministic_state_dict(seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Same recipe as deterministic_state_dict for the WindowTransformer keys (parameters only; the int64
+    ``relative_position_index`` buffers are created by the module)."""
+    sd: Dict[str, torch.Tensor] = OrderedDict()
+    shapes = wt_param_shapes()
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(("wt." + name).encode()) + 7919 * seed) & 0x7FFFFFFF)
+        if name.endswith("relative_position_bias_table"):
+            t = torch.randn(shape, generator=g) * 0.5
+        elif ".norm" in name and name.endswith("weight"):
+            t = 1.0 + (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif ".norm" in name:
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.2
+        elif name.endswith("bias"):
+            wname = name[:-4] + "weight"
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(_fan_in(wname, shapes[wname]))
+            if name == "decoder_conv2.bias":
+                t = t * 0.1
+        else:
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(_fan_in(name, shape))
+        sd[name] = t.to(dtype)
+    return sd

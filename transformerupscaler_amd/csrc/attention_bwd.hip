@@ -15,6 +15,14 @@
 
 namespace {
 
+// two 4-element fragments -> one 16x16x32 operand (x32 runs at twice the rate of the x16 MFMA on gfx950); both operands
+// of a product use the same k map, so any two 16-wide slices of the contracted axis can be paired
+TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
+    const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+}
+
+
 constexpr int DIM = 192, HEADS = 12, HD = 16, NTOK = 64;
 
 template <int NQ>
@@ -236,11 +244,18 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
             mrow[qt] = mx; irow[qt] = inv; drow[qt] = dsum;
             f32x4 dq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                f32x4 ds;
+            for (int kp = 0; kp < 2; ++kp) {
+                s16x4 dsb[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { ds[e] = st[kt][e] * (dpt[kt][e] - dsum); dbacc[kt][qt][e] += ds[e]; }
-                dq = mfma16x16x16(kT[kt], to_bf16x4(ds), dq);      // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kt = 2 * kp + hh;
+                    f32x4 ds;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ds[e] = st[kt][e] * (dpt[kt][e] - dsum); dbacc[kt][qt][e] += ds[e]; }
+                    dsb[hh] = to_bf16x4(ds);
+                }
+                // dQ^T[d][query] += K^T[d][key] dS^T[key][query], two key tiles per MFMA
+                dq = mfma16x16x32(join4(kT[2 * kp], kT[2 * kp + 1]), join4(dsb[0], dsb[1]), dq);
             }
             bf16_t* o = gqkv + ((size_t)win * NTOK + 16 * qt + p) * (3 * DIM) + h * HD + 4 * g;
             *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(dq[0] * 0.25f, dq[1] * 0.25f), pack_bf16x2(dq[2] * 0.25f, dq[3] * 0.25f)};
@@ -251,35 +266,44 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) { dvT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dkT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            float mr[4], ir[4], dr[4];
+        for (int qp = 0; qp < 2; ++qp) {            // dV / dK contract over queries: two query tiles per MFMA
+            float mr[2][4], ir[2][4], dr[2][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mr[e] = __shfl(mrow[qt], 4 * g + e);
-                ir[e] = __shfl(irow[qt], 4 * g + e);
-                dr[e] = __shfl(drow[qt], 4 * g + e);
-            }
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(bias_n + ((((size_t)h * 4 + qt) * 4 + kt) * 64 + lane) * 4);
-                const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
-                const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
-                f32x4 pr, ds;
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pr[e] = __expf(s[e] * 0.25f + bf[e] - mr[e]) * ir[e];
-                    float dpe = dp[e];
-                    if (drop_thresh) {
-                        const float m = drop_scale(drop_seed, (pair * 64u + 16u * qt + 4u * g + e) * 64u + 16u * kt + p, drop_thresh, drop_inv_keep);
-                        dpe *= m;
-                        ds[e] = pr[e] * (dpe - dr[e]);
-                        pr[e] *= m;                    // dV uses the dropped probabilities
-                    } else {
-                        ds[e] = pr[e] * (dpe - dr[e]);
-                    }
+                    mr[hh][e] = __shfl(mrow[2 * qp + hh], 4 * g + e);
+                    ir[hh][e] = __shfl(irow[2 * qp + hh], 4 * g + e);
+                    dr[hh][e] = __shfl(drow[2 * qp + hh], 4 * g + e);
                 }
-                dvT[kt] = mfma16x16x16(doT[qt], to_bf16x4(pr), dvT[kt]);   // dV^T[d][key] += dO^T[d][query] P[query][key]
-                dkT[kt] = mfma16x16x16(qT[qt], to_bf16x4(ds), dkT[kt]);    // dK^T[d][key] += Q^T[d][query] dS[query][key]
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                s16x4 prb[2], dsb[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int qt = 2 * qp + hh;
+                    const f32x4 bf = *reinterpret_cast<const f32x4*>(bias_n + ((((size_t)h * 4 + qt) * 4 + kt) * 64 + lane) * 4);
+                    const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 pr, ds;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pr[e] = __expf(s[e] * 0.25f + bf[e] - mr[hh][e]) * ir[hh][e];
+                        float dpe = dp[e];
+                        if (drop_thresh) {
+                            const float m = drop_scale(drop_seed, (pair * 64u + 16u * qt + 4u * g + e) * 64u + 16u * kt + p, drop_thresh, drop_inv_keep);
+                            dpe *= m;
+                            ds[e] = pr[e] * (dpe - dr[hh][e]);
+                            pr[e] *= m;                    // dV uses the dropped probabilities
+                        } else {
+                            ds[e] = pr[e] * (dpe - dr[hh][e]);
+                        }
+                    }
+                    prb[hh] = to_bf16x4(pr);
+                    dsb[hh] = to_bf16x4(ds);
+                }
+                dvT[kt] = mfma16x16x32(join4(doT[2 * qp], doT[2 * qp + 1]), join4(prb[0], prb[1]), dvT[kt]);   // dV^T += dO^T P
+                dkT[kt] = mfma16x16x32(join4(qT[2 * qp], qT[2 * qp + 1]), join4(dsb[0], dsb[1]), dkT[kt]);     // dK^T += Q^T dS
             }
         }
 #pragma unroll

@@ -9,6 +9,15 @@
 
 namespace {
 
+// Two 4-element fragments -> one v_mfma_f32_16x16x32_bf16 operand (twice the rate of the x16 form on gfx950): k index
+// 8g + j <-> element j of the first fragment (j < 4) or j - 4 of the second; both operands of a product use the same map,
+// so any two 16-wide slices of the contracted axis can be paired.
+TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
+    const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+    return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
+}
+
+
 constexpr int RD = 128, RH = 8, HD = 16;
 
 // ---- flash-style attention, one wave per (batch, head, 64-query tile); S^T tiles in registers, online softmax ----
@@ -95,17 +104,22 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= alpha;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                float pv[4];
+            for (int kp = 0; kp < 2; ++kp) {        // two key tiles per x32 MFMA
+                s16x4 pp[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { pv[e] = __expf(st[kt][qt][e] - mx); sum += pv[e]; }
-                if constexpr (DROP) {       // nn.MultiheadAttention drops the normalised probabilities: l keeps the full sum
-                    const uint32_t qi = (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + 4 * g);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kt = 2 * kp + hh;
+                    float pv[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pv[e] *= drop_scale(hseed, qi + e, thresh, inv_keep);
+                    for (int e = 0; e < 4; ++e) { pv[e] = __expf(st[kt][qt][e] - mx); sum += pv[e]; }
+                    if constexpr (DROP) {       // nn.MultiheadAttention drops the normalised probabilities: l keeps the full sum
+                        const uint32_t qi = (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[e] *= drop_scale(hseed, qi + e, thresh, inv_keep);
+                    }
+                    pp[hh] = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])});
                 }
-                const u32x2 pp = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
-                o = mfma16x16x16(vf[kt], __builtin_bit_cast(s16x4, pp), o);
+                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(pp[0], pp[1]), o);
             }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
@@ -319,19 +333,25 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-                const f32x4 dp = mfma16x16x16(vf[kt], dof[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-                f32x4 ds;
+            for (int kp = 0; kp < 2; ++kp) {        // dQ contracts over keys: two key tiles per x32 MFMA
+                s16x4 dsb[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + 16 * kt + 4 * g + e;
-                    const float pr = key < N ? __expf(s[e] * 0.25f - lc[qt]) : 0.f;
-                    float dpe = dp[e];
-                    if constexpr (DROP) dpe *= drop_scale(hseed, (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)key, thresh, inv_keep);
-                    ds[e] = pr * (dpe - dc[qt]);
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int kt = 2 * kp + hh;
+                    const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                    const f32x4 dp = mfma16x16x16(vf[kt], dof[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 ds;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = k0 + 16 * kt + 4 * g + e;
+                        const float pr = key < N ? __expf(s[e] * 0.25f - lc[qt]) : 0.f;
+                        float dpe = dp[e];
+                        if constexpr (DROP) dpe *= drop_scale(hseed, (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)key, thresh, inv_keep);
+                        ds[e] = pr * (dpe - dc[qt]);
+                    }
+                    dsb[hh] = f4_to_bf16x4(ds);
                 }
-                dq[qt] = mfma16x16x16(kT[kt], f4_to_bf16x4(ds), dq[qt]);
+                dq[qt] = mfma16x16x32(join4(kT[2 * kp], kT[2 * kp + 1]), join4(dsb[0], dsb[1]), dq[qt]);
             }
         wave_sync_lds();
     }
@@ -419,27 +439,34 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
             qT[t] = __builtin_bit_cast(s16x4, a); doT[t] = __builtin_bit_cast(s16x4, c);
         }
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
+        for (int qp = 0; qp < 2; ++qp)              // dV / dK contract over queries: two query tiles per x32 MFMA
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});       // rows query 4g+e, cols key p
-                const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
-                f32x4 pr, ds;
+                s16x4 prb[2], dsb[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int qq = q0 + 16 * qt + 4 * g + e;
-                    pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
-                    float dpe = dp[e];
-                    float keep = 1.0f;
-                    if constexpr (DROP) {
-                        keep = drop_scale(hseed, (uint32_t)qq * (uint32_t)N + (uint32_t)(k0 + 16 * kt + p), thresh, inv_keep);
-                        dpe *= keep;
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int qt = 2 * qp + hh;
+                    const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});       // rows query 4g+e, cols key p
+                    const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
+                    f32x4 pr, ds;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qq = q0 + 16 * qt + 4 * g + e;
+                        pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
+                        float dpe = dp[e];
+                        float keep = 1.0f;
+                        if constexpr (DROP) {
+                            keep = drop_scale(hseed, (uint32_t)qq * (uint32_t)N + (uint32_t)(k0 + 16 * kt + p), thresh, inv_keep);
+                            dpe *= keep;
+                        }
+                        ds[e] = pr[e] * (dpe - dr[qt][e]);
+                        pr[e] *= keep;                       // dV sees the dropped probabilities
                     }
-                    ds[e] = pr[e] * (dpe - dr[qt][e]);
-                    pr[e] *= keep;                       // dV sees the dropped probabilities
+                    prb[hh] = f4_to_bf16x4(pr);
+                    dsb[hh] = f4_to_bf16x4(ds);
                 }
-                dvT[kt] = mfma16x16x16(doT[qt], f4_to_bf16x4(pr), dvT[kt]);
-                dkT[kt] = mfma16x16x16(qT[qt], f4_to_bf16x4(ds), dkT[kt]);
+                dvT[kt] = mfma16x16x32(join4(doT[2 * qp], doT[2 * qp + 1]), join4(prb[0], prb[1]), dvT[kt]);
+                dkT[kt] = mfma16x16x32(join4(qT[2 * qp], qT[2 * qp + 1]), join4(dsb[0], dsb[1]), dkT[kt]);
             }
         wave_sync_lds();
     }

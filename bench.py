@@ -144,7 +144,7 @@ def main():
 
     def run_rt_train():
         """BASELINE.json configs[4]: ResidualTransformer 6x (720p -> 4320x7680) bf16 training step, 2 images/GPU, DP."""
-        import torch.nn.functional as F
+        from transformerupscaler_amd.autograd import l1_loss
         from transformerupscaler_amd.dp import DataParallel
         from transformerupscaler_amd.weights import rt_deterministic_state_dict
         tm = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
@@ -158,7 +158,7 @@ def main():
 
         def step():
             opt.zero_grad(set_to_none=True)
-            loss = F.l1_loss(tm(lr, upscale_factor=6), hr)
+            loss = l1_loss(tm(lr, upscale_factor=6), hr)          # nn.L1Loss (train.py:103,132) on the HIP kernels
             loss.backward()
             opt.step()
             return loss.detach()

@@ -292,6 +292,12 @@ int tup_wt_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, 
 int tup_wt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip, void* out,
                              int B, int Hs, int Ws, int K, void* stream);
 
+/* nn.L1Loss() of the training step (reference train.py:103,132) and its backward.  a, b fp32 [n] (n % 4 == 0):
+ * partial[nblocks] receives per-workgroup sums of |a - b| (the caller adds them and divides by n);
+ * ga = sign(a - b) * gout[0] / n. */
+int tup_l1_loss_partial(const float* a, const float* b, float* partial, long long n, int nblocks, void* stream);
+int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

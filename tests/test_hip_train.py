@@ -147,3 +147,18 @@ def test_adam_step_skips_unused_scales(det_sd, golden_dir):
     # second forward uses the updated weights (pack cache invalidated by the in-place update)
     l2 = train_loss(model, torch.from_numpy(d["lr"]).cuda(), torch.from_numpy(d["hr"]).cuda()).item()
     assert l2 < float(d["loss"]) + 1e-3
+
+
+def test_l1_loss_kernels_match_torch():
+    from transformerupscaler_amd.autograd import l1_loss
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand((2, 3, 54, 66), generator=g).cuda().requires_grad_(True)
+    b = torch.rand((2, 3, 54, 66), generator=g).cuda()
+    b.view(-1)[:5] = a.detach().view(-1)[:5]                 # exact ties: sign(0) = 0
+    loss = l1_loss(a, b)
+    (loss * 3.0).backward()
+    a2 = a.detach().clone().requires_grad_(True)
+    ref = F.l1_loss(a2, b)
+    (ref * 3.0).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6
+    assert torch.equal(a.grad, a2.grad)

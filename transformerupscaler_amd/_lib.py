@@ -50,6 +50,8 @@ SIGNATURES = {
     "tup_window_attn_fwd_h": [P, P, P, I, I, F, U, P],
     "tup_wt_patch_embed_fwd": [P, P, P, P, I, I, I, I, P],
     "tup_wt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, I, P],
+    "tup_l1_loss_partial": [P, P, P, c_longlong, I, P],
+    "tup_l1_loss_bwd": [P, P, P, P, c_longlong, P],
     "tup_u8hwc_to_f32chw": [P, P, I, I, I, I, P],
     "tup_f32chw_to_u8hwc": [P, P, I, I, I, I, P],
     "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],

@@ -251,3 +251,26 @@ def resize_aa(x: torch.Tensor, size) -> torch.Tensor:
     if tuple(x.shape[2:]) == tuple(size):
         return x
     return _ResizeAAFn.apply(x, tuple(size))
+
+
+class _L1LossFn(torch.autograd.Function):
+    """nn.L1Loss() (train.py:103,132) with a HIP forward and backward: two streaming passes instead of aten's six."""
+
+    @staticmethod
+    def forward(ctx, out, target):
+        out = out.contiguous().float()
+        target = target.contiguous().float()
+        ctx.save_for_backward(out, target)
+        part = ops.l1_loss_partial(out, target)
+        return (part.double().sum() / out.numel()).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, target = ctx.saved_tensors
+        return ops.l1_loss_bwd(out, target, g.contiguous().float().reshape(1)), None
+
+
+def l1_loss(out: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    if out.numel() % 4 != 0 or out.shape != target.shape:
+        return torch.nn.functional.l1_loss(out, target)       # shapes the kernels do not take: plumbing fallback, same math
+    return _L1LossFn.apply(out, target)

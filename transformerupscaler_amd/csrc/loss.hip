@@ -1,0 +1,63 @@
+// nn.L1Loss() of the training step (reference train.py:103,132: mean |output - target|) and its backward
+// (sign(output - target) * grad / N) as two streaming kernels.  aten evaluates the forward as sub, abs, mean and the
+// backward as sub, sign, mul -- six passes over tensors that are 796 MB each in the ResidualTransformer 6x step.
+// Bound: HBM (forward reads 2 tensors, backward reads 2 and writes 1).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ partial, size_t n4)
+{
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i], y = reinterpret_cast<const f32x4*>(b)[i];
+        acc += (fabsf(x[0] - y[0]) + fabsf(x[1] - y[1])) + (fabsf(x[2] - y[2]) + fabsf(x[3] - y[3]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ gout, float inv_n, float* __restrict__ ga, size_t n4)
+{
+    const float gs = gout[0] * inv_n;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i], y = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = x[e] - y[e]; o[e] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f); }
+        reinterpret_cast<f32x4*>(ga)[i] = o;
+    }
+}
+
+}  // namespace
+
+// partial[nblocks] = per-workgroup sums of |a - b| over n fp32 elements (n % 4 == 0); the caller adds them (in fp64) and
+// divides by n.  nblocks <= 65535.
+extern "C" int tup_l1_loss_partial(const float* a, const float* b, float* partial, long long n, int nblocks, void* stream)
+{
+    if (n <= 0) return 0;
+    if (n % 4 != 0 || nblocks < 1 || nblocks > 65535) return (int)hipErrorInvalidValue;
+    l1_partial_kernel<<<dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, partial, (size_t)(n / 4));
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ga = sign(a - b) * gout[0] / n  (gout: the scalar upstream gradient, on the device).
+extern "C" int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga, long long n, void* stream)
+{
+    if (n <= 0) return 0;
+    if (n % 4 != 0) return (int)hipErrorInvalidValue;
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    l1_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, gout, (float)(1.0 / (double)n), ga, (size_t)(n / 4));
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

@@ -637,3 +637,18 @@ def wt_patch_unembed(x, wt, bias, skip):
     _lib.call("tup_wt_patch_unembed_fwd", _chk(x, F32, (B * nwy * nwx * 64, K), "x"), _chk(wt, BF16, (4096, K), "wt"),
               _chk(bias, F32, (64,), "bias"), _chk(skip, BF16, None, "skip"), out.data_ptr(), B, Hs, Ws, K, _stream())
     return out
+
+
+# ---- training-step loss ----
+def l1_loss_partial(a, b, nblocks=2048):
+    n = a.numel()
+    part = torch.empty((nblocks,), dtype=F32, device=a.device)
+    _lib.call("tup_l1_loss_partial", _chk(a, F32, None, "a"), _chk(b, F32, tuple(a.shape), "b"), part.data_ptr(), n, nblocks, _stream())
+    return part
+
+
+def l1_loss_bwd(a, b, gout):
+    ga = torch.empty_like(a)
+    _lib.call("tup_l1_loss_bwd", _chk(a, F32, None, "a"), _chk(b, F32, tuple(a.shape), "b"), _chk(gout, F32, None, "gout"),
+              ga.data_ptr(), a.numel(), _stream())
+    return ga

@@ -495,6 +495,61 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
     }
 }
 
+// Separable form for large upscaling ratios (>= 3, e.g. the 6x configuration): a 16 x 64 output tile touches at most 16 source
+// rows of either source, so the horizontal interpolation is done once per (source row, output column) into LDS and the
+// vertical one reads it back -- ~6 FMAs and LDS reads per output instead of 32 FMAs + 48 global loads.  Same fmaf chains
+// as the direct kernel, so the results are identical.
+constexpr int BIC_TR = 16, BIC_MAXROWS = 16;
+__global__ __launch_bounds__(256) void rt_bicubic_sum_sep_kernel(
+    const float* __restrict__ a, const float* __restrict__ bsrc, float* __restrict__ out,
+    const int* __restrict__ ayi, const float* __restrict__ ayw, const int* __restrict__ axi, const float* __restrict__ axw,
+    const int* __restrict__ byi, const float* __restrict__ byw, const int* __restrict__ bxi, const float* __restrict__ bxw,
+    int Ha, int Wa, int Hb, int Wb, int Ho, int Wo, int clamp01)
+{
+    __shared__ float hbuf[2][BIC_MAXROWS][64];
+    const int col = threadIdx.x & 63, rsub = threadIdx.x >> 6;
+    const int ox = blockIdx.x * 64 + col, oxc = min(ox, Wo - 1);
+    const int oy0 = blockIdx.y * BIC_TR, oy1 = min(oy0 + BIC_TR, Ho) - 1;
+    const int plane = blockIdx.z;
+    const float* pa = a + (size_t)plane * Ha * Wa;
+    const float* pb = bsrc + (size_t)plane * Hb * Wb;
+    // source row ranges of the tile (tap tables are monotone, indices clamped)
+    const int ya0 = ayi[oy0 * 4], ya1 = ayi[oy1 * 4 + 3], yb0 = byi[oy0 * 4], yb1 = byi[oy1 * 4 + 3];
+    int xa[4], xb[4];
+    float wa[4], wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xa[j] = axi[oxc * 4 + j]; wa[j] = axw[oxc * 4 + j];
+        xb[j] = bxi[oxc * 4 + j]; wb[j] = bxw[oxc * 4 + j];
+    }
+    for (int r = rsub; r <= ya1 - ya0; r += 4) {
+        const float* ra = pa + (size_t)(ya0 + r) * Wa;
+        float h = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h = fmaf(wa[j], ra[xa[j]], h);
+        hbuf[0][r][col] = h;
+    }
+    for (int r = rsub; r <= yb1 - yb0; r += 4) {
+        const float* rb = pb + (size_t)(yb0 + r) * Wb;
+        float h = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h = fmaf(wb[j], rb[xb[j]], h);
+        hbuf[1][r][col] = h;
+    }
+    __syncthreads();
+    if (ox >= Wo) return;
+    for (int oy = oy0 + rsub; oy <= oy1; oy += 4) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc = fmaf(ayw[oy * 4 + i], hbuf[0][ayi[oy * 4 + i] - ya0][col], acc);
+            acc = fmaf(byw[oy * 4 + i], hbuf[1][byi[oy * 4 + i] - yb0][col], acc);
+        }
+        if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+        out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
+    }
+}
+
 // Backward of out = clamp(bicubic(a) + bicubic(b)) w.r.t. a, separable, in gather form: the clamp gate is read from
 // the saved output (0 < out < 1), pass 1 reduces output rows onto source rows (CSR lists per source row: which
 // output rows touch it and with what weight), pass 2 does the same along x.
@@ -575,8 +630,17 @@ extern "C" int tup_rt_bicubic_sum_fwd(const float* a, const float* b, float* out
 {
     if (planes <= 0) return 0;
     if (planes > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // 16 output rows span at most 16/ratio + 4 source rows (the separable kernel's LDS tile holds 16).  Measured: at
+    // ratio 6 / 12 (720p -> 8K) it is 1.9x faster than the direct kernel, at 1.5 / 3 (720p -> 1080p) 3x slower.
+    if (Ho >= 3 * Ha && Ho >= 3 * Hb && (Ho + BIC_TR - 1) / BIC_TR <= 65535) {
+        dim3 grid((Wo + 63) / 64, (Ho + BIC_TR - 1) / BIC_TR, planes);
+        rt_bicubic_sum_sep_kernel<<<grid, dim3(256), 0, s>>>(a, b, out, ayi, ayw, axi, axw, byi, byw, bxi, bxw, Ha, Wa, Hb, Wb, Ho, Wo, clamp01);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, planes);
-    rt_bicubic_sum_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+    rt_bicubic_sum_kernel<<<grid, dim3(256), 0, s>>>(
         a, b, out, ayi, ayw, axi, axw, byi, byw, bxi, bxw, Ha, Wa, Hb, Wb, Ho, Wo, clamp01);
     TUP_CHECK_LAUNCH();
     return 0;

@@ -298,6 +298,14 @@ int tup_wt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, 
 int tup_l1_loss_partial(const float* a, const float* b, float* partial, long long n, int nblocks, void* stream);
 int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga, long long n, void* stream);
 
+/* WindowTransformer backward pieces: the FastTransformer entries for `heads` = 8 or 12 and the window-layout patch weight
+ * gradient on the floor(H/8) x floor(W/8) token grid (out fp32 [NI][4096] += P^T patches(map), no reflect padding). */
+int tup_relpos_bias_expand_n_h(const float* table, float* frag, int heads, void* stream);
+int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t, const float* bias_n, void* gqkv,
+                          float* dbias_t, int nwin, int heads, float drop_p, unsigned int drop_seed, void* stream);
+int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int heads, void* stream);
+int tup_wt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int NI, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

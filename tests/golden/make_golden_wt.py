@@ -55,6 +55,26 @@ def main():
                                         (y == 1).double().mean().item()]),
                         row_means=y[0].double().mean(dim=(0, 2)).float().numpy())
     print("1080p", float(y.mean()))
+    # (3) one training-graph evaluation (eval graph = dropout off): L1 vs a seeded HR target on the cropped-skip geometry;
+    #     per parameter: gradient norm / abs-max, 64 sampled entries, full gradient of the small parameters
+    g = torch.Generator().manual_seed(4321)
+    lr = torch.rand((2, 3, 88, 120), generator=g)
+    hr = torch.rand((2, 3, 176, 240), generator=g)
+    model.zero_grad()
+    loss = torch.nn.functional.l1_loss(model(lr, upscale_factor=2), hr)
+    loss.backward()
+    d = {"loss": np.float64(loss.item()), "lr": lr.numpy(), "hr": hr.numpy()}
+    gi = torch.Generator().manual_seed(99)
+    for k, p in model.named_parameters():
+        gr = p.grad.detach().double().flatten()
+        idx = torch.randint(0, gr.numel(), (64,), generator=gi)
+        d["gstat_" + k] = np.array([gr.mean().item(), gr.norm().item(), gr.abs().max().item()])
+        d["gidx_" + k] = idx.numpy()
+        d["gval_" + k] = gr[idx].float().numpy()
+        if gr.numel() <= 4096:
+            d["gfull_" + k] = p.grad.detach().float().numpy()
+    np.savez_compressed(os.path.join(HERE, "wt_train_g88x120.npz"), **d)
+    print("train fixture: loss", loss.item())
 
 
 if __name__ == "__main__":

@@ -47,6 +47,10 @@ SIGNATURES = {
     "tup_conv3x3_c64_wgrad_s2d": [P, P, P, P, I, I, I, I, I, P],
     "tup_rt_bicubic_bwd": [P] * 10 + [I, I, I, I, I, P],
     "tup_relpos_bias_expand_h": [P, P, I, P],
+    "tup_relpos_bias_expand_n_h": [P, P, I, P],
+    "tup_window_attn_bwd_h": [P, P, P, P, P, P, I, I, F, U, P],
+    "tup_relpos_bias_reduce_h": [P, P, I, P],
+    "tup_wt_patch_wgrad": [P, P, P, I, I, I, I, P],
     "tup_window_attn_fwd_h": [P, P, P, I, I, F, U, P],
     "tup_wt_patch_embed_fwd": [P, P, P, P, I, I, I, I, P],
     "tup_wt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, I, P],

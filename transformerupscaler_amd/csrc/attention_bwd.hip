@@ -23,7 +23,7 @@ TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
 }
 
 
-constexpr int DIM = 192, HEADS = 12, HD = 16, NTOK = 64;
+constexpr int HD = 16, NTOK = 64;      // heads / width are template parameters (12 x 16 = 192, or 8 x 16 = 128)
 
 template <int NQ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 }
 
 // N-layout copy of the dense bias: fragN[h][qt][kt][lane][e] = bias(query 16qt+4g+e, key 16kt+l16)
+template <int HEADS>
 __global__ void relpos_expand_n_kernel(const float* __restrict__ table, float* __restrict__ frag)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -113,6 +114,7 @@ __global__ void relpos_expand_n_kernel(const float* __restrict__ table, float* _
 }
 
 // dtable[rel][h] = sum over (query, key) pairs with that relative offset of the dense T-layout gradient
+template <int HEADS>
 __global__ void relpos_reduce_kernel(const float* __restrict__ dfrag, float* __restrict__ dtable)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -146,11 +148,13 @@ TUP_DEVICE s16x4 to_bf16x4(const f32x4 v) {
     return __builtin_bit_cast(s16x4, p);
 }
 
+template <int HEADS>
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ gout, const float* __restrict__ bias_t,
     const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_t, int nwin, int nslots,
     uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
+    constexpr int DIM = HEADS * HD;
     __shared__ __attribute__((aligned(16))) bf16_t lds[4][3][NTOK * HD];     // per wave: K, Q, dO as [tok][hd]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
@@ -385,7 +389,57 @@ extern "C" int tup_layernorm128_bwd(const void* gy, const float* x, const float*
 // Dense bias in the N-layout fragment order (backward only): fp32 [12][4 qt][4 kt][64][4].
 extern "C" int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream)
 {
-    relpos_expand_n_kernel<<<dim3(HEADS * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(table, frag);
+    relpos_expand_n_kernel<12><<<dim3(12 * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(table, frag);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace {
+template <int HEADS>
+int launch_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n, void* gqkv, float* dbias_t,
+                    int nwin, float drop_p, unsigned int drop_seed, hipStream_t s)
+{
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    int nslots = nwin < 128 ? nwin : 128;
+    const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
+    window_attn_bwd_kernel<HEADS><<<dim3(nwaves / 4), dim3(256), 0, s>>>(
+        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, dbias_t, nwin, nslots,
+        thresh, 1.0f / (1.0f - drop_p), drop_seed);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace
+
+// The same three entry points for `heads` = 8 (WindowTransformer, width 128) or 12: table / dtable fp32 [225][heads],
+// frag / dbias_t fp32 [heads][4][4][64][4], qkv / gqkv bf16 [nwin][64][48*heads], gout bf16 [nwin][64][16*heads].
+extern "C" int tup_relpos_bias_expand_n_h(const float* table, float* frag, int heads, void* stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (heads == 12) relpos_expand_n_kernel<12><<<dim3(12 * 16), dim3(256), 0, s>>>(table, frag);
+    else if (heads == 8) relpos_expand_n_kernel<8><<<dim3(8 * 16), dim3(256), 0, s>>>(table, frag);
+    else return (int)hipErrorInvalidValue;
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
+                                     void* gqkv, float* dbias_t, int nwin, int heads, float drop_p, unsigned int drop_seed,
+                                     void* stream)
+{
+    if (nwin <= 0) return 0;
+    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (heads == 12) return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, nwin, drop_p, drop_seed, s);
+    if (heads == 8) return launch_attn_bwd<8>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, nwin, drop_p, drop_seed, s);
+    return (int)hipErrorInvalidValue;
+}
+
+extern "C" int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int heads, void* stream)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (heads == 12) relpos_reduce_kernel<12><<<dim3((225 * 12 + 255) / 256), dim3(256), 0, s>>>(dbias_t, dtable);
+    else if (heads == 8) relpos_reduce_kernel<8><<<dim3((225 * 8 + 255) / 256), dim3(256), 0, s>>>(dbias_t, dtable);
+    else return (int)hipErrorInvalidValue;
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -398,20 +452,13 @@ extern "C" int tup_window_attn_bwd(const void* qkv, const void* gout, const floa
 {
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    int nslots = nwin < 128 ? nwin : 128;
-    const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
-    window_attn_bwd_kernel<<<dim3(nwaves / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, dbias_t, nwin, nslots,
-        thresh, 1.0f / (1.0f - drop_p), drop_seed);
-    TUP_CHECK_LAUNCH();
-    return 0;
+    return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, nwin, drop_p, drop_seed, reinterpret_cast<hipStream_t>(stream));
 }
 
 // dense T-layout bias gradient -> relative_position_bias_table gradient fp32 [225][12] (overwritten).
 extern "C" int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream)
 {
-    relpos_reduce_kernel<<<dim3((225 * HEADS + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(dbias_t, dtable);
+    relpos_reduce_kernel<12><<<dim3((225 * 12 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(dbias_t, dtable);
     TUP_CHECK_LAUNCH();
     return 0;
 }

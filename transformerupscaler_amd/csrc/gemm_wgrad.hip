@@ -258,6 +258,19 @@ extern "C" int tup_rt_patch_wgrad(const float* P, const void* map, float* out, i
     return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
+// WindowTransformer's patch_embed / patch_unembed weights: out[NI][4096] += P^T patches(map), P fp32 [M][NI] token rows in
+// window layout over the floor(H/8) x floor(W/8) token grid (no reflect padding: pixels beyond the grid do not exist).
+extern "C" int tup_wt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int NI, void* stream)
+{
+    if (NI % 64 || H < 8 || W < 8) return (int)hipErrorInvalidValue;
+    WgradParams p{};
+    p.H = H; p.W = W; p.Ht = H / 8; p.Wt_ = W / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8; p.reflect = 0;
+    p.P = P; p.ldp = NI; p.Q = map; p.out = out; p.ldo = 4096;
+    p.M = B * p.nWy * p.nWx * 64; p.NI = NI; p.NJ = 4096;
+    return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
 // out[N] += column sums of G [M][N] (bias gradients); rowmask (uint8 [M], may be NULL) selects the rows
 // that count (patch_embed's bias does not reach the zero-padded tokens).
 extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, const void* rowmask, void* stream)

@@ -652,3 +652,53 @@ def l1_loss_bwd(a, b, gout):
     _lib.call("tup_l1_loss_bwd", _chk(a, F32, None, "a"), _chk(b, F32, tuple(a.shape), "b"), _chk(gout, F32, None, "gout"),
               ga.data_ptr(), a.numel(), _stream())
     return ga
+
+
+def relpos_bias_expand_n_h(table, heads):
+    frag = torch.empty((heads, 4, 4, 64, 4), dtype=F32, device=table.device)
+    _lib.call("tup_relpos_bias_expand_n_h", _chk(table, F32, (225, heads), "table"), frag.data_ptr(), heads, _stream())
+    return frag
+
+
+def window_attn_bwd_h(qkv, gout, bias_t, bias_n, heads, drop_p=0.0, drop_seed=0):
+    """returns (gqkv bf16 [M][48*heads], dtable fp32 [225][heads])."""
+    M = qkv.shape[0]
+    assert M % 64 == 0
+    gqkv = torch.empty((M, 48 * heads), dtype=BF16, device=qkv.device)
+    dbias = torch.zeros((heads, 4, 4, 64, 4), dtype=F32, device=qkv.device)
+    _lib.call("tup_window_attn_bwd_h", _chk(qkv, BF16, (M, 48 * heads), "qkv"), _chk(gout, BF16, (M, 16 * heads), "gout"),
+              _chk(bias_t, F32, (heads, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (heads, 4, 4, 64, 4), "bias_n"),
+              gqkv.data_ptr(), dbias.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+    dtable = torch.empty((225, heads), dtype=F32, device=qkv.device)
+    _lib.call("tup_relpos_bias_reduce_h", dbias.data_ptr(), dtable.data_ptr(), heads, _stream())
+    return gqkv, dtable
+
+
+def wt_patch_wgrad(p, fmap):
+    """fp32 [NI][4096] = p^T patches(fmap); p fp32 window-layout tokens [M][NI] over the floor(H/8) x floor(W/8) grid."""
+    B, H, W, C = fmap.shape
+    NI = p.shape[1]
+    out = torch.zeros((NI, 4096), dtype=F32, device=p.device)
+    _lib.call("tup_wt_patch_wgrad", _chk(p, F32, None, "p"), _chk(fmap, BF16, None, "map"), out.data_ptr(), B, H, W, NI, _stream())
+    return out
+
+
+def wt_patch_unembed_bwd(gmap, wd):
+    """d tokens (window layout, fp32 [M][N]) of the WindowTransformer patch_unembed: the patch_embed GEMM with W^T, no bias."""
+    B, H, W, C = gmap.shape
+    N = wd.shape[0]
+    nwy, nwx = (H // 8 + 7) // 8, (W // 8 + 7) // 8
+    x = torch.empty((B * nwy * nwx * 64, N), dtype=F32, device=gmap.device)
+    _lib.call("tup_wt_patch_embed_fwd", _chk(gmap, BF16, None, "gmap"), _chk(wd, BF16, (N, 4096), "wd"), None,
+              x.data_ptr(), B, H, W, N, _stream())
+    return x
+
+
+def wt_patch_embed_bwd(gx, wd, add):
+    """d feat_down on the token-covered map = add + scatter(gx wd^T) (the patch_unembed GEMM with W^T, no bias)."""
+    B, Hs, Ws, C = add.shape
+    K = wd.shape[1]
+    out = torch.empty_like(add)
+    _lib.call("tup_wt_patch_unembed_fwd", _chk(gx, F32, None, "gx"), _chk(wd, BF16, (4096, K), "wd"), None,
+              _chk(add, BF16, None, "add"), out.data_ptr(), B, Hs, Ws, K, _stream())
+    return out

@@ -288,7 +288,7 @@ def pack_rt_state_dict(sd: Dict[str, torch.Tensor], backward: bool = False) -> D
 # ------------------------------------------------------------------------------------------------
 # WindowTransformer
 # ------------------------------------------------------------------------------------------------
-def pack_wt_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+def pack_wt_state_dict(sd: Dict[str, torch.Tensor], backward: bool = False) -> Dict[str, torch.Tensor]:
     pk: Dict[str, torch.Tensor] = {}
     f32 = lambda t: t.detach().float().contiguous()
     t = lambda k: sd[k].detach()
@@ -310,4 +310,16 @@ def pack_wt_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     pk["pu.w"] = pack_linear(t("patch_unembed.weight").permute(2, 3, 1, 0).reshape(4096, dim)); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(t("decoder_conv1.weight"), t("decoder_conv1.bias"), 1)
     pk["dec2.w"] = pack_conv_c64_thin(t("decoder_conv2.weight")); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])
+    if not backward:
+        return pk
+    pk["conv2.wd"] = pack_conv_c64_dgrad(t("conv2.weight"), 1)
+    pk["ds.wd"] = pack_conv_c64_stride2_dgrad(t("downsample.weight"))
+    pk["dec1.wd"] = pack_conv_c64_dgrad(t("decoder_conv1.weight"), 1)
+    pk["dec2.wd"] = pack_conv_thin_dgrad(t("decoder_conv2.weight"))
+    pk["pe.wd"] = pack_linear(t("patch_embed.weight").permute(2, 3, 1, 0).reshape(4096, dim))      # rows (i,j,c), cols n
+    pk["pu.wd"] = pack_linear(t("patch_unembed.weight").permute(0, 2, 3, 1).reshape(dim, 4096))    # rows k, cols (i,j,o)
+    for i in range(nb):
+        p = f"window_blocks.{i}"
+        for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
+            pk[f"b{i}.{nm}.wd"] = pack_linear(t(f"{p}.{key}.weight").t().contiguous())
     return pk

@@ -1,9 +1,10 @@
 """``TransformerModel`` of the WindowTransformer plugin (reference models/WindowTransformer/model.py:172-305; SURVEY
-§8(f) rank 2) on the MI355X HIP kernels -- inference path.
+§8(f) rank 2) on the MI355X HIP kernels.
 
 Architecture = ResidualTransformer's shell (bicubic global residual, conv1/conv2, stride-2 downsample, patch_embed
 k8 s8 -> 128, patch_unembed, decoder convs) around FastTransformer's window blocks (8x8 windows, relative position
-bias) at width 128 / 8 heads, 8 blocks.  Same constructor keywords, forward signature and state_dict keys as the
+bias) at width 128 / 8 heads, 8 blocks.  With gradients enabled the call goes through autograd_wt (hand-written
+backward; dropout p = 0.01 in ``.train()`` as stateless hash masks).  Same constructor keywords, forward signature and state_dict keys as the
 reference (incl. the int64 ``relative_position_index`` buffers).  Arbitrary input sizes: the stride-8 patch conv drops
 the remainder rows / columns and the decoder runs on the cropped (H_t*8 x W_t*8) map, as the reference does.
 """
@@ -36,15 +37,30 @@ class TransformerModel(nn.Module):
         self.patch_unembed = _ConvParams(transformer_dim, base_channels, 8, transposed=True)
         self.decoder_conv1 = _ConvParams(base_channels, base_channels, 3)
         self.decoder_conv2 = _ConvParams(base_channels, in_channels, 3)
-        self._pack_cache = None
+        self._pack_cache = {}
+        self._dropout_calls = 0
 
-    def packed(self):
+    def _next_dropout(self):
+        """(p, seed) of the next training forward (see fast_transformer.TransformerModel._next_dropout)."""
+        if not self.training or self.dropout_p <= 0.0:
+            return 0.0, 0
+        import os
+        self._dropout_calls += 1
+        base = (torch.initial_seed() + 7919 * int(os.environ.get("RANK", "0"))) & 0x7FFFFFFF
+        return self.dropout_p, (base * 2654435761 + self._dropout_calls) & 0xFFFFFFFF
+
+    def packed(self, backward: bool = False):
+        """(packed weights, T-layout bias fragments[, N-layout fragments for the backward])."""
         ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if self._pack_cache is None or self._pack_cache[0] != ver:
-            pk = packing.pack_wt_state_dict(dict(self.named_parameters()))
+        hit = self._pack_cache.get(bool(backward))
+        if hit is None or hit[0] != ver:
+            pk = packing.pack_wt_state_dict(dict(self.named_parameters()), backward=backward)
             frags = [ops.relpos_bias_expand_h(pk[f"b{i}.table"], self.num_heads) for i in range(pk["nblocks"])]
-            self._pack_cache = (ver, pk, frags)
-        return self._pack_cache[1], self._pack_cache[2]
+            entry = (ver, pk, frags)
+            if backward:
+                entry += ([ops.relpos_bias_expand_n_h(pk[f"b{i}.table"], self.num_heads) for i in range(pk["nblocks"])],)
+            self._pack_cache[bool(backward)] = hit = entry
+        return hit[1:]
 
     def forward(self, x: torch.Tensor, res_out: Tuple[int, int] = (1080, 1920), upscale_factor: Optional[int] = None,
                 require_ratio: bool = True) -> torch.Tensor:
@@ -52,14 +68,18 @@ class TransformerModel(nn.Module):
             res_out = (x.shape[2] * upscale_factor, x.shape[3] * upscale_factor)          # model.py:236-237
         if not x.is_cuda:
             raise RuntimeError("TransformerModel (MI355X build) runs on the GPU only; there is no CPU fallback.")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("WindowTransformer: only the inference path is built; wrap the call in torch.no_grad()")
         B, _, H, W = x.shape
         if H % 2 or W % 2:
             raise NotImplementedError("odd input sizes (the stride-2 conv's ragged last row) are not built")
         hd, wd = H // 2, W // 2
         if hd < 8 or wd < 8:
             raise RuntimeError("input too small for one 8x8 patch after the stride-2 conv")    # the reference's conv fails too
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd_wt import window_transformer_function
+            out = window_transformer_function(self, x, tuple(int(v) for v in res_out))
+            return out.to(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else out
+        if self.training and self.dropout_p > 0.0:
+            raise NotImplementedError("WindowTransformer: .train() forward without gradients is not built; use .eval() under no_grad")
         pk, frags = self.packed()
         x = x.contiguous().float()
         feat = ops.conv_c64(ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True), pk["conv2.w"], pk["conv2.b"], 1, relu=True)

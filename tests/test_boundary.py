@@ -6,6 +6,7 @@ import inspect
 import os
 import re
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -170,3 +171,47 @@ def test_branch_a_composition_is_exact(r):
                 n = c * r * r + si * r + sj
                 out[0, c, Y, X] = (wc[n] * win).sum() + bc[n]
     assert (out - ref).abs().max() < 2e-4
+
+
+def test_transposed_bicubic_taps_are_the_adjoint():
+    """resize_taps.transpose_taps: the per-source CSR lists used by the gather-form bicubic backward are exactly the
+    transpose of the forward tap matrix, which itself reproduces F.interpolate(bicubic) (so the backward = autograd)."""
+    from transformerupscaler_amd.resize_taps import bicubic_taps, transpose_taps
+    for n_in, n_out in ((10, 47), (14, 66), (360, 1080)):
+        idx, w = bicubic_taps(n_in, n_out)
+        dense = np.zeros((n_out, n_in), dtype=np.float64)
+        for o in range(n_out):
+            for k in range(4):
+                dense[o, idx[o, k]] += w[o, k]
+        x = torch.rand(1, 1, n_in, 1, dtype=torch.float64)
+        ref = F.interpolate(x.float(), size=(n_out, 1), mode="bicubic", align_corners=False)[0, 0, :, 0].double().numpy()
+        assert np.abs(dense @ x[0, 0, :, 0].numpy() - ref).max() < 1e-5
+        start, oi, ow = transpose_taps(idx, w, n_in)
+        assert start[0] == 0 and start[-1] == 4 * n_out and np.all(np.diff(start) >= 0)
+        dense_t = np.zeros((n_in, n_out), dtype=np.float64)
+        for i in range(n_in):
+            for t in range(start[i], start[i + 1]):
+                dense_t[i, oi[t]] += ow[t]
+        assert np.array_equal(dense_t, dense.T)
+
+
+def test_stride2_dgrad_packing_matches_autograd():
+    """pack_conv_c64_stride2_dgrad: a 3x3 conv over the output gradient with one output tile per input sub-pixel, stored
+    through PixelShuffle(2), equals autograd of Conv2d(stride=2, padding=1) w.r.t. its input."""
+    from transformerupscaler_amd import packing
+    from transformerupscaler_amd.packing import _PERM64
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((1, 64, 12, 16), generator=g, requires_grad=True)
+    w = (torch.rand((64, 64, 3, 3), generator=g) - 0.5).to(torch.bfloat16).float()
+    y = F.conv2d(x, w, stride=2, padding=1)
+    gy = torch.rand(y.shape, generator=g) - 0.5
+    y.backward(gy)
+    wp = packing.pack_conv_c64_stride2_dgrad(w)[:, 0].float()            # [sub-pixel][tap][ci perm][co]
+    inv = torch.empty(64, dtype=torch.long); inv[_PERM64] = torch.arange(64)
+    wk = wp[:, :, inv, :]                                                # rows back in natural ci order
+    wfull = wk.permute(2, 0, 3, 1).reshape(64, 4, 64, 3, 3)              # [ci][sp][co][ky][kx]
+    planes = F.conv2d(gy, wfull.reshape(256, 64, 3, 3), padding=1)       # channel = ci*4 + sp
+    got = F.pixel_shuffle(planes, 2)
+    assert (got - x.grad).abs().max() <= 1e-4 * max(1.0, x.grad.abs().max().item())
+    dwp = torch.zeros(4, 64, 9, 64)
+    assert torch.equal(packing.unpack_conv_c64_stride2_wgrad(dwp), torch.zeros(64, 64, 3, 3))

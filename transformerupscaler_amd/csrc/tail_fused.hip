@@ -8,10 +8,12 @@
 // under that (+1 halo) -- three small LDS tiles, three barriers, and HBM sees only the LR residual, the
 // upscaled_input plane and the output.  Bound: HBM.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int OT_H = 16, OT_W = 64, NT = 512, NROW = NT / 64;     // 8 waves per workgroup
+__device__ unsigned long long tup_tail_stamps[16];        // timing experiments (TUP_TAIL_STAMPS=1): s_memtime per stage, one workgroup
 
 struct TailParams {
     const float* x;            // [B][3][H][W] input of the last final_upscale stage
@@ -23,12 +25,18 @@ struct TailParams {
     float* out;                // [B][3][Ho][Wo]
     const int* ymin; const int* ysize; const float* yw; int KY;
     const int* xmin; const int* xsize; const float* xw; int KX;
-    int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01;
+    int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01, stamps;
 };
 
-__global__ __launch_bounds__(NT) void tail_fused_kernel(const TailParams p)
+__global__ __launch_bounds__(NT, 4) void tail_fused_kernel(const TailParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float fl[];
+    int nst = 0;
+    auto stamp = [&]() {
+        if (p.stamps && blockIdx.x == 10 && blockIdx.y == 20 && blockIdx.z == 3 && threadIdx.x == 0) tup_tail_stamps[nst] = __builtin_amdgcn_s_memtime();
+        ++nst;
+    };
+    stamp();
     const int r = p.r, rr = r * r, nfu = 3 * rr;
     const int Hs = p.H * r, Ws = p.W * r;
     const int TH1 = p.EH + 2, TW1 = p.EW + 2;            // t1 tile (sum window + 3x3 halo)
@@ -61,12 +69,15 @@ __global__ __launch_bounds__(NT) void tail_fused_kernel(const TailParams p)
                 lr[(c * p.LH + yy) * p.LW + xx] =
                     (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix] : 0.f;
             }
+    stamp();          // 1: stage A loads issued + written
     __syncthreads();
+    stamp();          // 2: barrier
     // ---- stage B: t1 = PixelShuffle(conv3x3(x)) on the haloed HR window (zero outside the HR image).
     // A thread owns ONE sub-pixel phase (si, sj): its 81 weights live in registers and it walks LR pixels, so
     // the inner loop is 27 LDS reads per 81 FMAs (weights from LDS per FMA made this stage LDS-issue bound). ----
     for (int i = tid; i < 3 * TH1 * TW1; i += NT) t1[i] = 0.f;
     __syncthreads();
+    stamp();          // 3: t1 zeroed
     {
         const int nslots = NT / rr;
         const int ph = tid % rr, slot = tid / rr;
@@ -107,7 +118,9 @@ __global__ __launch_bounds__(NT) void tail_fused_kernel(const TailParams p)
             }
         }
     }
+    stamp();          // 4: stage B done
     __syncthreads();
+    stamp();          // 5: barrier
     // ---- stage C: sum = conv3x3(t1) + bias + upscaled_input on the HR window; the 81 weights are wave-uniform
     // (scalar loads straight from the kernel argument), the t1 taps come from LDS ----
     {
@@ -134,7 +147,9 @@ __global__ __launch_bounds__(NT) void tail_fused_kernel(const TailParams p)
             sm[2 * p.EH * p.EW + sy * p.EW + sx] = a2 + p.ui[o + 2 * (size_t)Hs * Ws];
         }
     }
+    stamp();          // 6: stage C done
     __syncthreads();
+    stamp();          // 7: barrier
     // ---- stage D: antialiased resize taps + clamp: a thread owns one output column (its x taps are loaded once) ----
     {
         const int ox = ox0 + t_col;
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(NT) void tail_fused_kernel(const TailParams p)
             }
         }
     }
+    stamp();          // 8: stage D done
 }
 
 }  // namespace
@@ -187,6 +203,8 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     p.x = x; p.wfu = wfu; p.bfu = bfu; p.wfc = wfc; p.bfc = bfc; p.ui = ui; p.out = out;
     p.ymin = ymin; p.ysize = ysize; p.yw = yw; p.KY = KY; p.xmin = xmin; p.xsize = xsize; p.xw = xw; p.KX = KX;
     p.H = H; p.W = W; p.r = r; p.Ho = Ho; p.Wo = Wo; p.EH = EH; p.EW = EW; p.clamp01 = clamp01;
+    static const int stamps_on = getenv("TUP_TAIL_STAMPS") ? 1 : 0;
+    p.stamps = stamps_on;
     p.LH = (EH + 2) / r + 4; p.LW = (EW + 2) / r + 4;
     const int nfu = 3 * r * r;
     const size_t lds = ((size_t)nfu * 29 + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW) * sizeof(float);
@@ -197,4 +215,10 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     tail_fused_kernel<<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
     TUP_CHECK_LAUNCH();
     return 0;
+}
+
+// Timing experiments only: s_memtime stamps of the last launch under TUP_TAIL_STAMPS=1 (9 values).
+extern "C" int tup_debug_tail_stamps(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_tail_stamps), sizeof(unsigned long long) * 16);
 }

@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 LR_H, LR_W, OUT = 720, 1280, (1080, 1920)
 CONV64_FLOP_PER_IMAGE = 2.0 * LR_H * LR_W * 64 * 576        # SURVEY 8(a) row E2 (conv2 64->64): 67.95 GFLOP / image
+ATTN_SET_FLOP_PER_IMAGE = 86.1e9                            # window-attention GEMM set (qkv, QK^T, PV, proj, fc1, fc2)
 
 
 def cpu_baseline(batch_images: int):
@@ -87,18 +88,18 @@ def main():
     g = torch.Generator().manual_seed(1234 + rank)
     x = torch.rand((args.batch, 3, LR_H, LR_W), generator=g).to(dev)      # resident in HBM before timing
 
-    events = []
+    events, block_events = [], []
 
     @contextlib.contextmanager
     def timer(name):
-        if name != "conv2" or not timing_on[0]:
+        if name not in ("conv2", "blocks") or not timing_on[0]:
             yield
             return
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()                       # current stream == the stream the kernel is launched on
         yield
         e.record()
-        events.append((s, e))
+        (events if name == "conv2" else block_events).append((s, e))
 
     timing_on = [False]
     engine.stage_timer = timer
@@ -239,6 +240,8 @@ def main():
     except Exception:
         traffic = None
     kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
+    blocks_ms = sum(s.elapsed_time(e) for s, e in block_events) / max(len(block_events), 1)
+    attn_set_tf = ATTN_SET_FLOP_PER_IMAGE * args.batch / (blocks_ms * 1e-3) / 1e12 if blocks_ms > 0 else 0.0
     achieved = CONV64_FLOP_PER_IMAGE * args.batch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
 
     if rank == 0:
@@ -260,6 +263,11 @@ def main():
                          "traffic_source": "profiles/r01_pmc_traffic_conv64.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                          "algorithmic_bytes": 2 * args.batch * LR_H * LR_W * 64 * 2,
                          "ms_per_launch": kern_ms, "launches_timed": len(events)},
+            # the north-star's second ask: MFMA utilisation of the window-attention GEMM set (the 6 transformer blocks,
+            # 24 launches per forward, event-timed as one stage; includes their LayerNorm / softmax / GELU work)
+            "attention_gemm_set": {"achieved": attn_set_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": attn_set_tf / MFMA_BF16_PEAK_TFLOPS, "ms_per_forward": blocks_ms,
+                                   "gflop_per_image": ATTN_SET_FLOP_PER_IMAGE / 1e9},
         }
         if train_result is not None:
             out["train"] = train_result

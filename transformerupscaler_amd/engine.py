@@ -102,7 +102,8 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
     xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])
     if cap is not None:
         cap["win_in"] = xw.clone()
-    xw = transformer_blocks(pk, xw, bias_frags, cap)
+    with _stage("blocks"):
+        xw = transformer_blocks(pk, xw, bias_frags, cap)
     combined = ops.patch_unembed(xw, pk["pu.w"], pk["pu.b"], feat)
     dec = ops.conv_c64(combined, pk["dec1.w"], pk["dec1.b"], 1, relu=True)
     residual = ops.conv_c64_thin(dec, pk["dec2.w"], pk["dec2.b"], 3, relu=False)

@@ -567,11 +567,167 @@ __global__ __launch_bounds__(256, 2) void gemm_panel_kernel(const GemmParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Panel kernel v2 (K = 192): the token operand never touches LDS.  Each lane loads its 32 rows directly in MFMA
+// B-fragment order (token 16tg+pl, channels 32*step + 8g .. +8; A_LN: statistics by two cross-lane-group shuffles) and
+// keeps the 12 bf16x8 fragments in registers for all N/64 weight tiles.  LDS holds only the weight stream: two 24 KB
+// buffers filled by LDS-DMA one tile ahead, ONE workgroup barrier per tile (v1: global -> registers -> ds_write, two
+// barriers).  K loop: weight fragments two K-steps ahead, immediate-offset reads.  Epilogue operands are requested
+// before the K loop (epi_prefetch).  48 KB of LDS, <= 256 VGPRs: two 4-wave workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_panel2_kernel(const GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x PW_BYTES
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    const int m0 = blockIdx.x * PBM;
+    const int ntiles = p.N / 64;
+
+    // weight tile nt -> LDS buffer: slot s = u*256 + tid -> k-tile u >> 1, row (u & 1)*32 + (tid >> 3), logical chunk
+    // (tid & 7) ^ ((tid >> 4) & 7) (swizzle on the source side); six pieces per thread, compile-time offsets
+    const bf16_t* w_thr = p.Wt + (size_t)(tid >> 3) * PK + ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+    auto dma_w = [&](int nt, int buf) {
+        char* dst = smem + buf * PW_BYTES + wave * 1024;
+        const bf16_t* src = w_thr + (size_t)nt * 64 * PK;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * PK + (u >> 1) * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+    };
+    dma_w(0, 0);
+
+    // ---- token fragments ----
+    bf16x8 tf[2][6];
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg) {
+        const int m = min(m0 + 32 * wave + 16 * tg + pl, p.M - 1);
+        if constexpr (AMODE == A_BF16) {
+            const bf16_t* ar = (const bf16_t*)p.A + (size_t)m * p.lda + 8 * g;
+#pragma unroll
+            for (int st = 0; st < 6; ++st) tf[tg][st] = *reinterpret_cast<const bf16x8*>(ar + 32 * st);
+        } else {
+            const float* xr = (const float*)p.A + (size_t)m * p.lda + 8 * g;
+            f32x4 v[6][2];
+            float sum = 0.f;
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                v[st][0] = *reinterpret_cast<const f32x4*>(xr + 32 * st);
+                v[st][1] = *reinterpret_cast<const f32x4*>(xr + 32 * st + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += v[st][0][e] + v[st][1][e];
+            }
+            float mean = 0.f, rstd = 1.f;
+            if constexpr (AMODE == A_LN) {
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                mean = sum * (1.0f / PK);
+                float ss = 0.f;
+#pragma unroll
+                for (int st = 0; st < 6; ++st)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float d = v[st][h][e] - mean; ss += d * d; }
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                rstd = rsqrtf(ss * (1.0f / PK) + 1e-5f);
+            }
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float o4[4];
+                    if constexpr (AMODE == A_LN) {
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_gamma + 32 * st + 8 * g + 4 * h);
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_beta + 32 * st + 8 * g + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = (v[st][h][e] - mean) * rstd * gm[e] + bt[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = v[st][h][e];
+                    }
+                    pk[2 * h] = pack_bf16x2(o4[0], o4[1]);
+                    pk[2 * h + 1] = pack_bf16x2(o4[2], o4[3]);
+                }
+                tf[tg][st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+            }
+        }
+    }
+
+    const uint32_t w_frag = lds_addr(smem) + (uint32_t)swz128(pl, g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of W tile 0
+    for (int nt = 0; nt < ntiles; ++nt) {
+        __syncthreads();                                       // everyone's pieces of tile nt landed; everyone finished reading tile nt-1
+        if (nt + 1 < ntiles) dma_w(nt + 1, (nt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int n0 = nt * 64;
+        float bvec[16];
+        gemm_load_bias(p, n0, g, EPI == E_UNEMBED, bvec);
+        EpiPre pre[2];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) pre[tg] = epi_prefetch<EPI>(p, min(m0 + 32 * wave + 16 * tg + pl, p.M - 1), n0, g);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const uint32_t wb = w_frag + (uint32_t)((nt & 1) * PW_BYTES);
+            bf16x8 wf[3][4];
+            auto ld = [&](int step, int slot) {
+                const int kc = step >> 1;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    wf[slot][ct] = (step & 1) ? lds_read_b128_asm_off_x64(wb, kc * (64 * 128) + ct * 2048)
+                                              : lds_read_b128_asm_off(wb, kc * (64 * 128) + ct * 2048);
+            };
+            ld(0, 0);
+            ld(1, 1);
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int cur = step % 3;
+                if (step + 2 < 6) { ld(step + 2, (step + 2) % 3); lds_wait<8>(); }
+                else if (step + 1 < 6) { lds_wait<4>(); }
+                else { lds_wait<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = mfma16x16x32(wf[cur][ct], tf[tg][step], acc[tg][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // Own pieces of W tile nt+1 (requested a K loop ago) and the epilogue operands: waited for HERE, before this
+        // tile's stores are issued -- a vmcnt(0) at the top of the next iteration would also wait for those stores.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            const int m = m0 + 32 * wave + 16 * tg + pl;
+            if (m >= p.M) continue;
+            float v[16];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ct][e];
+            epi_finish<EPI>(p, m, n0, g, v, bvec, pre[tg]);
+        }
+    }
+}
+
 template <int AMODE, int EPI>
 int launch_panel(const GemmParams& p, hipStream_t s)
 {
     if (p.M <= 0) return 0;
     if (p.N % 64 != 0 || p.K != PK) return (int)hipErrorInvalidValue;
+    static const bool use_v1 = (getenv("TUP_GEMM_PANEL_V1") != nullptr);
+    if (!use_v1) {
+        gemm_panel2_kernel<AMODE, EPI><<<dim3((p.M + PBM - 1) / PBM), dim3(256), 2 * PW_BYTES, s>>>(p);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     constexpr size_t lds = PA_BYTES + PW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {

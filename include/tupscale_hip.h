@@ -306,6 +306,13 @@ int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t
 int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int heads, void* stream);
 int tup_wt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int NI, void* stream);
 
+/* Inference fusion of norm1 + attn.qkv + the WindowAttention core (models/FastTransformer/model.py:104-130,163): the qkv
+ * tensor never exists.  x fp32 [64*nwin][192] (window layout); wh bf16 [12][64][192] = per head the q, k, v weight rows
+ * (16 each, natural channel order) + 16 zero rows; bh fp32 [12][48]; bias_frag from tup_relpos_bias_expand;
+ * out bf16 [64*nwin][192] (the input of attn.proj). */
+int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const float* beta, const void* wh, const float* bh,
+                           const float* bias_frag, void* out, int nwin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

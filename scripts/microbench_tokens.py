@@ -38,3 +38,7 @@ a_ = ops.window_attn(ops.gemm_tokens(y_, wq, bq, "bf16"), frag)
 print("attn core   %.1f us" % timeit(lambda: ops.window_attn(ops.gemm_tokens(y_, wq, bq, "bf16"), frag)))
 print("proj+res    %.1f us" % timeit(lambda: ops.gemm_tokens(a_, wp, bp, "res", res=x, out=x)))
 print("fc1 gelu    %.1f us" % timeit(lambda: ops.gemm_tokens(y_, w1, b1, "gelu")))
+from transformerupscaler_amd import packing as _pk
+_wh, _bh = _pk.pack_qkv_heads(torch.randn(576, 192) * 0.07, torch.randn(576) * 0.1)
+_wh, _bh = _wh.cuda(), _bh.cuda()
+print("fused ln+qkv+attn %.1f us" % timeit(lambda: ops.fused_qkv_attn(x, gm, bt, _wh, _bh, frag)))

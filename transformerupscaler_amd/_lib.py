@@ -54,6 +54,7 @@ SIGNATURES = {
     "tup_window_attn_fwd_h": [P, P, P, I, I, F, U, P],
     "tup_wt_patch_embed_fwd": [P, P, P, P, I, I, I, I, P],
     "tup_wt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, I, P],
+    "tup_fused_qkv_attn_fwd": [P, P, P, P, P, P, P, I, P],
     "tup_l1_loss_partial": [P, P, P, c_longlong, I, P],
     "tup_l1_loss_bwd": [P, P, P, P, c_longlong, P],
     "tup_u8hwc_to_f32chw": [P, P, I, I, I, I, P],

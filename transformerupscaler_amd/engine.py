@@ -6,6 +6,8 @@ maps, fp32 planar for the 3-channel images, fp32 residual stream for the tokens.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, Optional, Tuple
 
@@ -17,6 +19,7 @@ from .weights import BLOCKS, VALID_SCALES, upsampler_layout
 
 # Optional per-stage timing hook (bench.py installs one): callable(name) -> context manager.
 stage_timer = None
+fuse_attention = os.environ.get("TUP_NO_FUSED_ATTN") is None        # norm1 + qkv + attention in one kernel (inference)
 
 
 class _NullCtx:
@@ -49,12 +52,17 @@ fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     for i in range(BLOCKS):
-        if fuse_blocks:
-            qkv = ops.ln_gemm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"])
+        qkv = None
+        if fuse_blocks and fuse_attention and capture is None and f"b{i}.qkv.wh" in pk:
+            # norm1 + qkv + attention core in one kernel (the qkv tensor never exists)
+            att = ops.fused_qkv_attn(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i])
         else:
-            y = ops.layernorm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"])
-            qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
-        att = ops.window_attn(qkv, bias_frags[i])
+            if fuse_blocks:
+                qkv = ops.ln_gemm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"])
+            else:
+                y = ops.layernorm(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"])
+                qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
+            att = ops.window_attn(qkv, bias_frags[i])
         ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=x, out=x)
         if fuse_blocks:
             ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"],

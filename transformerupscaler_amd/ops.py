@@ -209,6 +209,17 @@ def ln_gemm(x, gamma, beta, wt, bias):
     return out
 
 
+def fused_qkv_attn(x, gamma, beta, wh, bh, bias_frag):
+    """bf16 [M][192] = attention core of qkv(LayerNorm(x)) per 8x8 window (inference fusion; the qkv tensor never exists)."""
+    M = x.shape[0]
+    assert M % 64 == 0
+    out = torch.empty((M, 192), dtype=BF16, device=x.device)
+    _lib.call("tup_fused_qkv_attn_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma, F32, (192,), "gamma"), _chk(beta, F32, (192,), "beta"),
+              _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
+              out.data_ptr(), M // 64, _stream())
+    return out
+
+
 def fused_mlp(x, gamma, beta, w1, b1, w2, b2):
     """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip)."""
     M = x.shape[0]

@@ -65,6 +65,17 @@ def pack_linear(weight: torch.Tensor):
     return perm_rows64(weight).contiguous().to(torch.bfloat16)
 
 
+def pack_qkv_heads(weight: torch.Tensor, bias: torch.Tensor, heads: int = 12):
+    """attn.qkv Linear [3*dim][dim] -> per head the 16 q, 16 k, 16 v weight rows in natural channel order + 16 zero rows:
+    bf16 [heads][64][dim], and the matching biases fp32 [heads][48] (tup_fused_qkv_attn_fwd)."""
+    dim = weight.shape[1]
+    w = weight.detach().reshape(3, heads, 16, dim).permute(1, 0, 2, 3).reshape(heads, 48, dim)
+    wh = torch.zeros(heads, 64, dim, dtype=weight.dtype, device=weight.device)
+    wh[:, :48] = w
+    bh = bias.detach().reshape(3, heads, 16).permute(1, 0, 2).reshape(heads, 48).float().contiguous()
+    return wh.contiguous().to(torch.bfloat16), bh
+
+
 def pack_patch_embed(weight: torch.Tensor):
     """Conv2d(64,192,k8,s8) weight [192][64][8][8] -> bf16 [192][4096], k = (i*8+j)*64 + c."""
     return pack_linear(weight.permute(0, 2, 3, 1).reshape(192, 4096))
@@ -172,6 +183,9 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
             pk[f"b{i}.{nm}.w"] = pack_linear(sd[f"{p}.{key}.weight"].detach())
             pk[f"b{i}.{nm}.b"] = f32(sd[f"{p}.{key}.bias"])
+    if not backward:      # inference fusion of norm1 + qkv + attention
+        for i in range(BLOCKS):
+            pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"window_blocks.{i}.attn.qkv.weight"], sd[f"window_blocks.{i}.attn.qkv.bias"])
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
     pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])

@@ -28,7 +28,8 @@ struct TailParams {
     int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01, stamps;
 };
 
-__global__ __launch_bounds__(NT, 4) void tail_fused_kernel(const TailParams p)
+template <int OCC>
+__global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float fl[];
     int nst = 0;
@@ -209,10 +210,18 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     const int nfu = 3 * r * r;
     const size_t lds = ((size_t)nfu * 29 + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, two 512-thread workgroups per CU) or 2
+    static const bool occ2 = getenv("TUP_TAIL_OCC2") != nullptr;
     dim3 grid((Wo + OT_W - 1) / OT_W, (Ho + OT_H - 1) / OT_H, B);
-    tail_fused_kernel<<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
+    if (occ2) {
+        hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        tail_fused_kernel<2><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
+    } else {
+        hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        tail_fused_kernel<4><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
+    }
     TUP_CHECK_LAUNCH();
     return 0;
 }

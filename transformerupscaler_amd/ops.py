@@ -368,6 +368,19 @@ def conv_thin_wgrad(x, gpl, want_bias):
 
 
 def conv1_wgrad(x, gmap):
+    """Weight / bias gradient of conv1 (3 -> 64): x planar fp32 [B][3][H][W], gmap NHWC bf16 [B][H][W][64].
+    dw[co][ci][tap] = sum_p g[p][co] x[p + tap - 1][ci] = sum_q x[q][ci] g[q - (tap - 1)][co]: the thin (cout = 3) MFMA weight-
+    gradient kernel with the roles of the two maps swapped and the taps flipped, plus a column sum for the bias."""
+    B, C, H, W = x.shape
+    assert C == 3
+    dwp, _ = conv_thin_wgrad(gmap, x, False)                     # [ci][tap'][co], tap' = 8 - tap
+    dw = dwp.flip(1).permute(2, 0, 1).reshape(64, 3, 3, 3)
+    db = colsum(gmap.view(-1, 64))
+    return dw, db
+
+
+def conv1_wgrad_direct(x, gmap):
+    """The original VALU kernel (tup_conv3x3_c3_wgrad), kept for the kernel-level test."""
     B, C, H, W = x.shape
     assert C == 3
     dw = torch.zeros((64, 3, 3, 3), dtype=F32, device=x.device)

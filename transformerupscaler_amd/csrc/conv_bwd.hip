@@ -344,6 +344,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(
 //          G_pre[c*r*r + sp][y][x] = G[c][y*r+si][x*r+sj]   (G planar fp32 [B][3][H*r][W*r]).
 // One thread per output element (co, ci, tap) / bias, looping over the pixels of an LDS tile.
 // ------------------------------------------------------------------------------------------------
+// v2: a thread owns one sub-pixel phase (si, sj) and walks LR pixels, holding the phase's 3 x 27 partial weight
+// gradients (+ 3 bias sums) in registers for its whole persistent run: 30 LDS reads per 81 FMAs.  (v1 gave each THREAD
+// one (cout, tap) output and looped it over the tile's pixels -- 84 of 256 threads busy at r = 1, two LDS reads per FMA;
+// 0.7 ms per call.)  The per-thread sums are combined through LDS float atomics once at the end.
 __global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
     const float* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dw, float* __restrict__ dbias,
     int B, int H, int W, int r, int th, int tilesX, int tilesY)
@@ -352,12 +356,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
     const int cout = 3 * r * r, rr = r * r;
     float* x_lds = fl;                               // [3][th+2][HALO_W]
     float* g_lds = fl + 3 * (th + 2) * HALO_W;       // [cout][th*32]
+    float* red = g_lds + cout * th * 32;             // [rr][84]
     const int npix = th * 32;
-    const int nout = cout * 28;                      // 27 weights + 1 bias per cout
     const int tid = threadIdx.x;
-    float acc[12];
+    const int nslot = 256 / rr;
+    const int ph = tid % rr, slot = tid / rr;
+    const bool worker = slot < nslot;
+    float acc[3][27], bsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[c][k] = 0.f;
+    for (int i = tid; i < rr * 84; i += 256) red[i] = 0.f;
     const int Hr = H * r, Wr = W * r;
     const int ntiles = tilesX * tilesY * B;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -375,38 +385,43 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
         for (int idx = tid; idx < cout * npix; idx += 256) {
             const int co = idx / npix, pix = idx - co * npix;
             const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
-            const int c = co / rr, s = co - c * rr;
-            const int si = s / r, sj = s - si * r;
+            const int c = co / rr, s2 = co - c * rr;
+            const int si = s2 / r, sj = s2 - si * r;
             g_lds[idx] = (oy < H && ox < W) ? gpl[(((size_t)b * 3 + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] : 0.f;
         }
         __syncthreads();
+        if (worker)
+            for (int pix = slot; pix < npix; pix += nslot) {
+                const float g0 = g_lds[(0 * rr + ph) * npix + pix], g1 = g_lds[(1 * rr + ph) * npix + pix],
+                            g2 = g_lds[(2 * rr + ph) * npix + pix];
+                bsum[0] += g0; bsum[1] += g1; bsum[2] += g2;
+                const float* xp = x_lds + (pix >> 5) * HALO_W + (pix & 31);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int o = tid + i * 256;
-            if (o < nout) {
-                const int co = o / 28, k = o - co * 28;
-                const float* gp = g_lds + co * npix;
-                float s = 0.f;
-                if (k < 27) {
-                    const int ci = k / 9, tap = k - ci * 9;
-                    const float* xp = x_lds + (ci * (th + 2) + tap / 3) * HALO_W + tap % 3;
-                    for (int pix = 0; pix < npix; ++pix) s = fmaf(gp[pix], xp[(pix >> 5) * HALO_W + (pix & 31)], s);
-                } else {
-                    for (int pix = 0; pix < npix; ++pix) s += gp[pix];
-                }
-                acc[i] += s;
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const float v = xp[(ci * (th + 2) + tap / 3) * HALO_W + tap % 3];
+                        const int k = ci * 9 + tap;
+                        acc[0][k] = fmaf(g0, v, acc[0][k]); acc[1][k] = fmaf(g1, v, acc[1][k]); acc[2][k] = fmaf(g2, v, acc[2][k]);
+                    }
             }
-        }
         __syncthreads();
     }
+    if (worker) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int o = tid + i * 256;
-        if (o < nout) {
-            const int co = o / 28, k = o - co * 28;
-            if (k < 27) atomicAdd(dw + co * 27 + k, acc[i]);
-            else if (dbias) atomicAdd(dbias + co, acc[i]);
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 27; ++k) atomicAdd(red + ph * 84 + c * 28 + k, acc[c][k]);
+            atomicAdd(red + ph * 84 + c * 28 + 27, bsum[c]);
         }
+    }
+    __syncthreads();
+    for (int o = tid; o < rr * 84; o += 256) {
+        const int p2 = o / 84, rem = o - p2 * 84;
+        const int c = rem / 28, k = rem - c * 28;
+        const int co = c * rr + p2;
+        if (k < 27) atomicAdd(dw + co * 27 + k, red[o]);
+        else if (dbias) atomicAdd(dbias + co, red[o]);
     }
 }
 
@@ -625,7 +640,7 @@ extern "C" int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float*
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + th - 1) / th;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const size_t lds = ((size_t)3 * (th + 2) * HALO_W + (size_t)cout * th * 32) * sizeof(float);
+    const size_t lds = ((size_t)3 * (th + 2) * HALO_W + (size_t)cout * th * 32 + (size_t)r * r * 84) * sizeof(float);
     conv3x3_wgrad_planar_kernel<<<dim3(persistent_grid(nt, 4)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
         x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
     TUP_CHECK_LAUNCH();

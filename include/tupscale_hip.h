@@ -313,6 +313,11 @@ int tup_wt_patch_wgrad(const float* P, const void* map, float* out, int B, int H
 int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const float* beta, const void* wh, const float* bh,
                            const float* bias_frag, void* out, int nwin, void* stream);
 
+/* ... and with attn.proj + the residual add as well (the attention half of a block, model.py:163-164), x updated in place.
+ * wproj bf16 [192][192] from packing.pack_proj_pairs (rows permuted per 64-group, columns in head-pair K order). */
+int tup_fused_attn_block_fwd(float* x, const float* gamma, const float* beta, const void* wh, const float* bh,
+                             const float* bias_frag, const void* wproj, const float* bproj, int nwin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -444,3 +444,31 @@ def test_fused_qkv_attention(dev, nwin):
     got = ops.fused_qkv_attn(x.to(dev), gm.to(dev), bt.to(dev), wh.to(dev), bh.to(dev), frag).float().cpu()
     err = (got - ref).abs().max().item()
     assert err <= 3e-2 + 2e-2 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("nwin", [2, 5, 64])
+def test_fused_attention_block(dev, nwin):
+    """x += proj(attention(qkv(LN(x)))) + b in one kernel vs torch."""
+    from transformerupscaler_amd import ops, packing
+    g = torch.Generator().manual_seed(22)
+    M = nwin * 64
+    x = torch.randn((M, 192), generator=g)
+    gm = 1 + 0.1 * torch.randn(192, generator=g); bt = 0.1 * torch.randn(192, generator=g)
+    w = torch.randn((576, 192), generator=g) / 192 ** 0.5; b = 0.1 * torch.randn(576, generator=g)
+    wp = torch.randn((192, 192), generator=g) / 192 ** 0.5; bp = 0.1 * torch.randn(192, generator=g)
+    table = 0.5 * torch.randn((225, 12), generator=g)
+    y = F.layer_norm(x, (192,), gm, bt, 1e-5).to(torch.bfloat16).float()
+    qkv = (y @ w.to(torch.bfloat16).float().t() + b).view(nwin, 64, 3, 12, 16).permute(2, 0, 3, 1, 4)
+    ys, xs = torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij")
+    ys, xs = ys.flatten(), xs.flatten()
+    idx = (ys[:, None] - ys[None, :] + 7) * 15 + (xs[:, None] - xs[None, :] + 7)
+    bias = table[idx.view(-1)].view(64, 64, 12).permute(2, 0, 1)
+    attn = torch.softmax((qkv[0] * 0.25) @ qkv[1].transpose(-2, -1) + bias, dim=-1)
+    att = (attn @ qkv[2]).transpose(1, 2).reshape(M, 192).to(torch.bfloat16).float()
+    ref = x + att @ wp.to(torch.bfloat16).float().t() + bp
+    wh, bh = packing.pack_qkv_heads(w, b)
+    frag = ops.relpos_bias_expand(table.to(dev))
+    got = ops.fused_attn_block(x.to(dev).clone(), gm.to(dev), bt.to(dev), wh.to(dev), bh.to(dev), frag,
+                               packing.pack_proj_pairs(wp).to(dev), bp.to(dev)).cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 3e-2 + 2e-2 * ref.abs().max().item(), err

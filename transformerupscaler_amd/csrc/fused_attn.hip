@@ -41,10 +41,14 @@ TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
 }
 __device__ __attribute__((aligned(16))) unsigned int tup_fa_sink[64 * 2];       // store sink of inactive lanes (fixed vmcnt)
 
+// PROJ = true additionally runs attn.proj + the residual add (model.py:131,164) on the attention output while it is still
+// in registers: the 12 per-head O^T tiles ARE the token fragments of that GEMM (two heads = one K-step of 32, weight
+// columns pre-permuted to match), W_proj streams through the two weight slots in 3 chunks, and x is updated in place.
+template <bool PROJ>
 __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const bf16_t* __restrict__ wh, const float* __restrict__ bh, const float* __restrict__ bias_frag,
-    bf16_t* __restrict__ out, int nwin)
+    bf16_t* __restrict__ out, int nwin, const bf16_t* __restrict__ wproj, const float* __restrict__ bproj, float* __restrict__ xio)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -125,10 +129,21 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const uint32_t v_rd = 2048 + (uint32_t)(4 * g + trq) * 32 + trp * 8;      // + 16*kt*32: V rows 16kt+4g+trq (transposed read)
     bf16_t* sink = reinterpret_cast<bf16_t*>(tup_fa_sink) + lane * 4;
 
+    // PROJ: the attention output of this wave's 32 tokens, all heads: of[tg][h] = O^T tile (channels 4g.., token pl) as bf16x4
+    s16x4 of[2][PROJ ? HEADS : 1];
+    const bf16_t* wp_thr = PROJ ? wproj + (size_t)(tid >> 3) * DIM + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 : nullptr;
+    auto dma_wp = [&](int chunk, int buf) {                      // rows 64*chunk .. +63 of the packed proj weight
+        char* dst = smem + buf * FW_BYTES + wave * 1024;
+        const bf16_t* src = wp_thr + (size_t)chunk * 64 * DIM;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+    };
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of head 0's weights; bias staging visible below
     __syncthreads();
-#pragma unroll 1
-    for (int h = 0; h < HEADS; ++h) {
+    auto head = [&](const int h) {
         // relative position bias of this wave's (key tile, query tile) pairs, requested BEFORE the DMA below so that the
         // compiler's wait for them is vmcnt(6) (= the DMA pieces), not vmcnt(0)
         f32x4 rb[2][4];
@@ -140,12 +155,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         __builtin_amdgcn_sched_barrier(0);
         if (h > 0) {
             // own pieces of head h's weights (requested one head ago): younger than them are the 2 output stores of head
-            // h-1 and the 8 loads above
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            // h-1 (none with PROJ) and the 8 loads above
+            if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone finished head h-1's reads
         }
         if (h + 1 < HEADS) dma_w(h + 1, (h + 1) & 1);
+        else if constexpr (PROJ) dma_wp(0, 0);                  // slot 0 is free (head 10 is done everywhere): first proj chunk
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- [q; k; v]^T = W_h LN(x)^T: rows = channel within the head (ct 0 = q, 1 = k, 2 = v), columns = tokens ----
@@ -196,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                          // both halves of every window have written K, V
+        if constexpr (PROJ) { if (h + 1 == HEADS) dma_wp(1, 1); }       // slot 1 (head 11's weights) is free now: second proj chunk
         s16x4 kf[4], vf[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -239,8 +257,77 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(pp[0], pp[1]), o);
             }
             // O^T tile: rows = channel 4g+e, column = query pl  ->  out[row][h*16 + 4g .. +3]
-            bf16_t* op = active ? out + (size_t)(row0 + 16 * tg + pl) * DIM + h * HD + 4 * g : sink;
-            *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            if constexpr (PROJ) {
+                of[tg][h] = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])});
+            } else {
+                bf16_t* op = active ? out + (size_t)(row0 + 16 * tg + pl) * DIM + h * HD + 4 * g : sink;
+                *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            }
+        }
+    };
+    if constexpr (PROJ) {
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) head(h);               // unrolled: of[tg][h] must be a register, not an indexed array
+    } else {
+#pragma unroll 1
+        for (int h = 0; h < HEADS; ++h) head(h);
+    }
+
+    if constexpr (PROJ) {
+        // ---- x += att W_proj^T + b: K-step p = heads (2p, 2p+1); the packed weight has its columns ordered to match
+        // join4's k map, so the fragment addressing is the standard one (k-tile p >> 1, chunk 4 (p & 1) + g) ----
+        f32x4 acc2[2][12];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+            for (int n = 0; n < 12; ++n) acc2[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of chunk c
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everyone's pieces; everyone finished chunk c-1
+            if (c == 1) dma_wp(2, 0);
+            const uint32_t wb = sbase + (uint32_t)((c & 1) * FW_BYTES) + w_off;
+            bf16x8 wf[3][4];
+            auto ld = [&](int step, int slot) {
+                const int kc = step >> 1;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    wf[slot][ct] = (step & 1) ? lds_read_b128_asm_off_x64(wb, kc * (64 * 128) + ct * 2048)
+                                              : lds_read_b128_asm_off(wb, kc * (64 * 128) + ct * 2048);
+            };
+            ld(0, 0);
+            ld(1, 1);
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int cur = step % 3;
+                if (step + 2 < 6) { ld(step + 2, (step + 2) % 3); lds_wait<8>(); }
+                else if (step + 1 < 6) { lds_wait<4>(); }
+                else { lds_wait<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tg = 0; tg < 2; ++tg) {
+                    const bf16x8 tfp = join4(of[tg][2 * step], of[tg][2 * step + 1]);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc2[tg][4 * c + ct] = mfma16x16x32(wf[cur][ct], tfp, acc2[tg][4 * c + ct]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!active) return;
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+#pragma unroll
+            for (int n = 0; n < 12; ++n) {
+                const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;       // weight rows are permuted per 64-group
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + col);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bproj + col);
+                f32x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = acc2[tg][n][e] + bv[e] + rv[e];
+                *reinterpret_cast<f32x4*>(xr + col) = ov;
+            }
         }
     }
 }
@@ -256,12 +343,30 @@ extern "C" int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const 
     if (nwin <= 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    fused_qkv_attn_kernel<<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, (bf16_t*)out, nwin);
+    fused_qkv_attn_kernel<false><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
+        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, (bf16_t*)out, nwin, nullptr, nullptr, nullptr);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// The whole attention half of a block, in place: x += proj(attention(qkv(LayerNorm1(x)))) + b_proj (model.py:163-164).
+// wproj bf16 [192][192]: attn.proj.weight with rows permuted per 64-group and columns ordered by packing.pack_proj_pairs.
+extern "C" int tup_fused_attn_block_fwd(float* x, const float* gamma, const float* beta, const void* wh, const float* bh,
+                                        const float* bias_frag, const void* wproj, const float* bproj, int nwin, void* stream)
+{
+    if (nwin <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    fused_qkv_attn_kernel<true><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
+        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x);
     TUP_CHECK_LAUNCH();
     return 0;
 }

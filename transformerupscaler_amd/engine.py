@@ -19,7 +19,9 @@ from .weights import BLOCKS, VALID_SCALES, upsampler_layout
 
 # Optional per-stage timing hook (bench.py installs one): callable(name) -> context manager.
 stage_timer = None
-fuse_attention = os.environ.get("TUP_NO_FUSED_ATTN") is None        # norm1 + qkv + attention in one kernel (inference)
+# inference fusion level of the attention half: 2 = norm1 + qkv + attention + proj + residual in one kernel,
+# 1 = norm1 + qkv + attention (proj separate), 0 = separate kernels
+fuse_attention = 0 if os.environ.get("TUP_NO_FUSED_ATTN") else int(os.environ.get("TUP_FUSED_ATTN_LEVEL", "2"))
 
 
 class _NullCtx:
@@ -53,6 +55,13 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     for i in range(BLOCKS):
         qkv = None
+        if fuse_blocks and fuse_attention == 2 and capture is None and f"b{i}.proj.wpp" in pk:
+            # the whole attention half in one kernel, in place: neither the qkv nor the attention-output tensor exists
+            ops.fused_attn_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
+                                 pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"])
+            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"],
+                          pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
+            continue
         if fuse_blocks and fuse_attention and capture is None and f"b{i}.qkv.wh" in pk:
             # norm1 + qkv + attention core in one kernel (the qkv tensor never exists)
             att = ops.fused_qkv_attn(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i])

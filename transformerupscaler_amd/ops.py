@@ -220,6 +220,16 @@ def fused_qkv_attn(x, gamma, beta, wh, bh, bias_frag):
     return out
 
 
+def fused_attn_block(x, gamma, beta, wh, bh, bias_frag, wproj, bproj):
+    """In place: x += proj(attention(qkv(LayerNorm(x)))) + b_proj (the attention half of a block, inference fusion)."""
+    M = x.shape[0]
+    assert M % 64 == 0
+    _lib.call("tup_fused_attn_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma, F32, (192,), "gamma"), _chk(beta, F32, (192,), "beta"),
+              _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
+              _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"), M // 64, _stream())
+    return x
+
+
 def fused_mlp(x, gamma, beta, w1, b1, w2, b2):
     """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip)."""
     M = x.shape[0]

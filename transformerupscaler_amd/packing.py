@@ -76,6 +76,19 @@ def pack_qkv_heads(weight: torch.Tensor, bias: torch.Tensor, heads: int = 12):
     return wh.contiguous().to(torch.bfloat16), bh
 
 
+def pack_proj_pairs(weight: torch.Tensor):
+    """attn.proj weight [dim][dim] for tup_fused_attn_block_fwd: rows permuted per 64-group (as pack_linear) and, inside every
+    32-column block (= two heads), columns reordered so that lane group g's eight K values are contiguous:
+    new column 32p + 8g + j  <-  old 32p + 4g + j (j < 4, head 2p) | 32p + 16 + 4g + (j - 4) (j >= 4, head 2p + 1)."""
+    dim = weight.shape[1]
+    idx = torch.empty(dim, dtype=torch.long)
+    for p in range(dim // 32):
+        for g in range(4):
+            for j in range(8):
+                idx[32 * p + 8 * g + j] = 32 * p + 4 * g + j if j < 4 else 32 * p + 16 + 4 * g + (j - 4)
+    return perm_rows64(weight.detach()[:, idx.to(weight.device)]).contiguous().to(torch.bfloat16)
+
+
 def pack_patch_embed(weight: torch.Tensor):
     """Conv2d(64,192,k8,s8) weight [192][64][8][8] -> bf16 [192][4096], k = (i*8+j)*64 + c."""
     return pack_linear(weight.permute(0, 2, 3, 1).reshape(192, 4096))
@@ -186,6 +199,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
     if not backward:      # inference fusion of norm1 + qkv + attention
         for i in range(BLOCKS):
             pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"window_blocks.{i}.attn.qkv.weight"], sd[f"window_blocks.{i}.attn.qkv.bias"])
+            pk[f"b{i}.proj.wpp"] = pack_proj_pairs(sd[f"window_blocks.{i}.attn.proj.weight"])
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
     pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])

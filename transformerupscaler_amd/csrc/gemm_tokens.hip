@@ -752,6 +752,167 @@ int launch(const GemmParams& p, hipStream_t s)
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// patch_embed (K = 4096 gathered from the NHWC map) as its own kernel: one workgroup = 8 waves = 256 tokens x ALL N/64
+// feature groups, so every 8x8 patch is fetched once (the generic 128 x 64 tile above reads it N/64 times through L2 and
+// runs 16 MFMAs per barrier).  One K-step = one patch pixel (64 channels): token tile 32 KB + weight tile N x 128 B, both
+// by LDS-DMA (swizzle and the reflect / zero padding on the source side) into a two-stage ring, one barrier per K-step;
+// a wave owns 32 tokens x N: per quarter K-step 2 token + 6 (4) weight fragments for 12 (8) MFMAs, fragments two quarter
+// steps ahead, immediate-offset reads.
+// ------------------------------------------------------------------------------------------------
+constexpr int PE_BM = 256, PE_A_BYTES = PE_BM * 128;
+__device__ __attribute__((aligned(16))) unsigned int tup_pe_zero_line[4] = {0u, 0u, 0u, 0u};
+
+template <int NT64>
+__global__ __launch_bounds__(512, 2) void patch_embed_kernel(const GemmParams p)
+{
+    constexpr int NTILE = 4 * NT64;                        // 16-row weight tiles
+    constexpr int W_BYTES = NT64 * 64 * 128, STAGE = PE_A_BYTES + W_BYTES;
+    constexpr int QN = NTILE / 2;                          // weight tiles per quarter step
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // 2 x STAGE
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, pl = lane & 15;
+    const int m0 = blockIdx.x * PE_BM;
+    const int nk = p.K / 64;                               // 64 patch pixels
+
+    // ---- DMA bookkeeping: token-tile slot s = u*512 + tid -> row u*64 + (tid >> 3), logical chunk below ----
+    const int dc = (tid & 7) ^ ((tid >> 4) & 7);
+    uint32_t tokoff[4];                                    // byte offset of the patch origin (+ chunk) in the map
+    int tpy[4], tpx[4];
+    bool tval[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int m = min(m0 + u * 64 + (tid >> 3), p.M - 1);
+        const TokPos t = token_of_row(m, p);
+        tval[u] = t.valid && (m0 + u * 64 + (tid >> 3) < p.M);
+        tpy[u] = t.ty * 8; tpx[u] = t.tx * 8;
+        tokoff[u] = (uint32_t)(((size_t)t.b * p.H) * p.W * 128) + dc * 16;
+    }
+    const bf16_t* w_thr = p.Wt + (size_t)(tid >> 3) * p.K + dc * 8;
+    auto dma_stage = [&](int kc, int buf) {
+        char* dst = smem + buf * STAGE + wave * 1024;
+        const int i = kc >> 3, j = kc & 7;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int py = tpy[u] + i, px = tpx[u] + j;
+            bool ok = tval[u];
+            if (p.reflect) {
+                if (py >= p.H) py = 2 * p.H - 2 - py;
+                if (px >= p.W) px = 2 * p.W - 2 - px;
+            } else if (py >= p.H || px >= p.W) {
+                ok = false;
+            }
+            const char* src = ok ? (const char*)p.A + tokoff[u] + (size_t)(py * p.W + px) * 128 : (const char*)tup_pe_zero_line;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + u * 8192), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NT64; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_thr + (size_t)u * 64 * p.K + kc * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + PE_A_BYTES + u * 8192), 16, 0, 0);
+    };
+    dma_stage(0, 0);
+
+    f32x4 acc[2][NTILE];
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int n = 0; n < NTILE; ++n) acc[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t sbase = lds_addr(smem);
+    const uint32_t a_off0 = (uint32_t)swz128(32 * wave + pl, g), a_off1 = (uint32_t)swz128(32 * wave + 16 + pl, g);
+    const uint32_t w_off = (uint32_t)(PE_A_BYTES + swz128(pl, g));
+
+    for (int kc = 0; kc < nk; ++kc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of stage kc
+        __syncthreads();                                       // everyone's; everyone finished reading stage kc-1
+        if (kc + 1 < nk) dma_stage(kc + 1, (kc + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t sb = sbase + (uint32_t)((kc & 1) * STAGE);
+        // quarter steps q = 0..3: K half kh = q >> 1, weight tiles (q & 1)*QN .. +QN
+        bf16x8 tf[3][2], wf[3][QN];
+        auto ld = [&](int q, int slot) {
+            const int nb = (q & 1) * QN;
+            if (q >> 1) {
+                tf[slot][0] = lds_read_b128_asm_off_x64(sb + a_off0, 0);
+                tf[slot][1] = lds_read_b128_asm_off_x64(sb + a_off1, 0);
+#pragma unroll
+                for (int n = 0; n < QN; ++n) wf[slot][n] = lds_read_b128_asm_off_x64(sb + w_off, (nb + n) * 2048);
+            } else {
+                tf[slot][0] = lds_read_b128_asm_off(sb + a_off0, 0);
+                tf[slot][1] = lds_read_b128_asm_off(sb + a_off1, 0);
+#pragma unroll
+                for (int n = 0; n < QN; ++n) wf[slot][n] = lds_read_b128_asm_off(sb + w_off, (nb + n) * 2048);
+            }
+        };
+        constexpr int PER = 2 + QN;
+        ld(0, 0);
+        ld(1, 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cur = q % 3;
+            if (q + 2 < 4) { ld(q + 2, (q + 2) % 3); lds_wait<(2 * PER > 15 ? 15 : 2 * PER)>(); }
+            else if (q + 1 < 4) { lds_wait<PER>(); }
+            else { lds_wait<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            const int nb = (q & 1) * QN;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                for (int n = 0; n < QN; ++n) acc[tg][nb + n] = mfma16x16x32(wf[cur][n], tf[cur][tg], acc[tg][nb + n]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: per 64-feature group the lane holds features n0 + g*16 + ct*4 + e of token row m ----
+#pragma unroll
+    for (int ng = 0; ng < NT64; ++ng) {
+        float bvec[16];
+        gemm_load_bias(p, ng * 64, g, false, bvec);
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            const int m = m0 + 32 * wave + 16 * tg + pl;
+            if (m >= p.M) continue;
+            float v[16];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ng * 4 + ct][e];
+            gemm_store_row<E_PATCH_EMBED>(p, m, ng * 64, g, v, bvec);
+        }
+    }
+}
+
+template <int NT64>
+int launch_patch_embed(const GemmParams& p, hipStream_t s)
+{
+    if (p.M <= 0) return 0;
+    constexpr size_t lds = 2 * (size_t)(PE_A_BYTES + NT64 * 64 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)patch_embed_kernel<NT64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    patch_embed_kernel<NT64><<<dim3((p.M + PE_BM - 1) / PE_BM), dim3(512), lds, s>>>(p);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_patch_embed_any(const GemmParams& p, hipStream_t s)
+{
+    static const bool use_old = (getenv("TUP_PATCH_EMBED_V1") != nullptr);
+    // the kernel keeps 32-bit byte offsets into the map: fine up to 4 GB of NHWC bf16 (B*H*W < 33.5 M pixels)
+    const long long per_img = p.linear_tokens ? (long long)p.Ht * p.Wt_ : (long long)p.nWy * p.nWx * 64;
+    const long long nimg = per_img > 0 ? p.M / per_img : 0;
+    const bool fits = nimg * (long long)p.H * p.W * 128 < (1LL << 32);
+    if (!use_old && fits && p.K == 4096) {
+        if (p.N == 192) return launch_patch_embed<3>(p, s);
+        if (p.N == 128) return launch_patch_embed<2>(p, s);
+    }
+    return launch<A_PATCH, E_PATCH_EMBED>(p, s);
+}
+
 }  // namespace
 
 // epilogue: 0 = (+bias) -> bf16, 1 = +bias, erf-GELU -> bf16, 2 = +bias +res(fp32) -> fp32,
@@ -814,7 +975,7 @@ extern "C" int tup_patch_embed_fwd(const void* feat, const void* Wt, const float
     p.M = B * p.nWy * p.nWx * 64; p.N = 192; p.K = 4096; p.reflect = 1;
     // reflect padding needs pad < dim (same constraint as F.pad(mode='reflect'))
     if ((p.Ht * 8 - H) >= H || (p.Wt_ * 8 - W) >= W) return (int)hipErrorInvalidValue;
-    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+    return launch_patch_embed_any(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // x: fp32 [B*nWy*nWx*64][192] window layout.  Wt: [4096][192] bf16, n = (i*8+j)*64 + o (rows permuted
@@ -854,7 +1015,7 @@ extern "C" int tup_patch_unembed_bwd(const void* gmap, const void* Wt, float* gx
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = gmap; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = gx; p.ldo = 192;
     p.M = B * p.nWy * p.nWx * 64; p.N = 192; p.K = 4096; p.reflect = 0;
-    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+    return launch_patch_embed_any(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Backward of patch_embed w.r.t. the (reflect-padded) feature map (model.py:256-285 under autograd):
@@ -881,7 +1042,7 @@ extern "C" int tup_rt_patch_embed_fwd(const void* feat, const void* Wt, const fl
     p.H = H; p.W = W; p.Ht = H / 8; p.Wt_ = W / 8; p.linear_tokens = 1; p.pos = pos; p.reflect = 0;
     p.A = feat; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = x_out; p.ldo = 128;
     p.M = B * p.Ht * p.Wt_; p.N = 128; p.K = 4096;
-    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+    return launch_patch_embed_any(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // x fp32 [B*T][128]; Wt bf16 [4096][128] (n = (i*8+j)*64 + o); out = skip + ConvTranspose(k8,s8)(x) + bias, NHWC bf16.
@@ -910,7 +1071,7 @@ extern "C" int tup_wt_patch_embed_fwd(const void* feat, const void* Wt, const fl
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8; p.reflect = 0;
     p.A = feat; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = x_out; p.ldo = N;
     p.M = B * p.nWy * p.nWx * 64; p.N = N; p.K = 4096;
-    return launch<A_PATCH, E_PATCH_EMBED>(p, reinterpret_cast<hipStream_t>(stream));
+    return launch_patch_embed_any(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // window_reverse + crop + patch_unembed + skip (model.py:272-291): x fp32 window layout [M][K], Wt bf16 [4096][K],

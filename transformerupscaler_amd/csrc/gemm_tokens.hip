@@ -763,7 +763,9 @@ int launch(const GemmParams& p, hipStream_t s)
 constexpr int PE_BM = 256, PE_A_BYTES = PE_BM * 128;
 __device__ __attribute__((aligned(16))) unsigned int tup_pe_zero_line[4] = {0u, 0u, 0u, 0u};
 
-template <int NT64>
+// AMODE = A_PATCH (gathered patches) or A_BF16 (plain bf16 rows [M][lda]: the K = 576 / 768 Linear layers of the training
+// path with N = 192), EPI = any epilogue of gemm_store_row.
+template <int NT64, int AMODE, int EPI>
 __global__ __launch_bounds__(512, 2) void patch_embed_kernel(const GemmParams p)
 {
     constexpr int NTILE = 4 * NT64;                        // 16-row weight tiles
@@ -780,13 +782,19 @@ __global__ __launch_bounds__(512, 2) void patch_embed_kernel(const GemmParams p)
     uint32_t tokoff[4];                                    // byte offset of the patch origin (+ chunk) in the map
     int tpy[4], tpx[4];
     bool tval[4];
+    const char* arow[4];                                   // A_BF16: this thread's four rows (+ chunk)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int m = min(m0 + u * 64 + (tid >> 3), p.M - 1);
-        const TokPos t = token_of_row(m, p);
-        tval[u] = t.valid && (m0 + u * 64 + (tid >> 3) < p.M);
-        tpy[u] = t.ty * 8; tpx[u] = t.tx * 8;
-        tokoff[u] = (uint32_t)(((size_t)t.b * p.H) * p.W * 128) + dc * 16;
+        tval[u] = m0 + u * 64 + (tid >> 3) < p.M;
+        if constexpr (AMODE == A_PATCH) {
+            const TokPos t = token_of_row(m, p);
+            tval[u] = tval[u] && t.valid;
+            tpy[u] = t.ty * 8; tpx[u] = t.tx * 8;
+            tokoff[u] = (uint32_t)(((size_t)t.b * p.H) * p.W * 128) + dc * 16;
+        } else {
+            arow[u] = (const char*)p.A + (size_t)m * p.lda * 2 + dc * 16;
+        }
     }
     const bf16_t* w_thr = p.Wt + (size_t)(tid >> 3) * p.K + dc * 8;
     auto dma_stage = [&](int kc, int buf) {
@@ -794,15 +802,20 @@ __global__ __launch_bounds__(512, 2) void patch_embed_kernel(const GemmParams p)
         const int i = kc >> 3, j = kc & 7;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            int py = tpy[u] + i, px = tpx[u] + j;
-            bool ok = tval[u];
-            if (p.reflect) {
-                if (py >= p.H) py = 2 * p.H - 2 - py;
-                if (px >= p.W) px = 2 * p.W - 2 - px;
-            } else if (py >= p.H || px >= p.W) {
-                ok = false;
+            const char* src;
+            if constexpr (AMODE == A_PATCH) {
+                int py = tpy[u] + i, px = tpx[u] + j;
+                bool ok = tval[u];
+                if (p.reflect) {
+                    if (py >= p.H) py = 2 * p.H - 2 - py;
+                    if (px >= p.W) px = 2 * p.W - 2 - px;
+                } else if (py >= p.H || px >= p.W) {
+                    ok = false;
+                }
+                src = ok ? (const char*)p.A + tokoff[u] + (size_t)(py * p.W + px) * 128 : (const char*)tup_pe_zero_line;
+            } else {
+                src = tval[u] ? arow[u] + (size_t)kc * 128 : (const char*)tup_pe_zero_line;
             }
-            const char* src = ok ? (const char*)p.A + tokoff[u] + (size_t)(py * p.W + px) * 128 : (const char*)tup_pe_zero_line;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + u * 8192), 16, 0, 0);
         }
@@ -878,23 +891,23 @@ __global__ __launch_bounds__(512, 2) void patch_embed_kernel(const GemmParams p)
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ng * 4 + ct][e];
-            gemm_store_row<E_PATCH_EMBED>(p, m, ng * 64, g, v, bvec);
+            gemm_store_row<EPI>(p, m, ng * 64, g, v, bvec);
         }
     }
 }
 
-template <int NT64>
+template <int NT64, int AMODE = A_PATCH, int EPI = E_PATCH_EMBED>
 int launch_patch_embed(const GemmParams& p, hipStream_t s)
 {
     if (p.M <= 0) return 0;
     constexpr size_t lds = 2 * (size_t)(PE_A_BYTES + NT64 * 64 * 128);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)patch_embed_kernel<NT64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)patch_embed_kernel<NT64, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    patch_embed_kernel<NT64><<<dim3((p.M + PE_BM - 1) / PE_BM), dim3(512), lds, s>>>(p);
+    patch_embed_kernel<NT64, AMODE, EPI><<<dim3((p.M + PE_BM - 1) / PE_BM), dim3(512), lds, s>>>(p);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -950,6 +963,11 @@ extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const vo
             if (epilogue == 3) return launch_panel<A_F32, E_GELU_BWD>(p, s);
         }
         return (int)hipErrorInvalidValue;
+    }
+    static const bool use_big = (getenv("TUP_GEMM_NOBIG") == nullptr);
+    if (use_big && a_dtype == 0 && N == 192 && K > PK && K % 64 == 0 && M >= 4096) {       // long-K Linear layers onto the big tile
+        if (epilogue == 0) return launch_patch_embed<3, A_BF16, E_BF16>(p, s);
+        if (epilogue == 2) return launch_patch_embed<3, A_BF16, E_RES_F32>(p, s);
     }
     if (a_dtype == 0) {
         if (epilogue == 0) return launch<A_BF16, E_BF16>(p, s);

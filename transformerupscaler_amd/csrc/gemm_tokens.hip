@@ -1046,6 +1046,8 @@ extern "C" int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_p
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = gx; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = gmap_pad; p.skip = nullptr;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
+    static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
+    if (use_panel) return launch_panel<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                                              (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
     };
     dma_w(0, 0);
+    dma_w(1, 1);
 
     // ---- LayerNorm1 straight into B fragments: token 16tg+pl, channels 32*st + 8g .. +8 ----
     bf16x8 tf[2][6];
@@ -153,17 +154,6 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             for (int kt = 0; kt < 4; ++kt)
                 rb[tg][kt] = *reinterpret_cast<const f32x4*>(bias_frag + ((((size_t)h * 4 + kt) * 4 + (2 * hf + tg)) * 64 + lane) * 4);
         __builtin_amdgcn_sched_barrier(0);
-        if (h > 0) {
-            // own pieces of head h's weights (requested one head ago): younger than them are the 2 output stores of head
-            // h-1 (none with PROJ) and the 8 loads above
-            if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone finished head h-1's reads
-        }
-        if (h + 1 < HEADS) dma_w(h + 1, (h + 1) & 1);
-        else if constexpr (PROJ) dma_wp(0, 0);                  // slot 0 is free (head 10 is done everywhere): first proj chunk
-        __builtin_amdgcn_sched_barrier(0);
 
         // ---- [q; k; v]^T = W_h LN(x)^T: rows = channel within the head (ct 0 = q, 1 = k, 2 = v), columns = tokens ----
         const uint32_t wb = sbase + (uint32_t)((h & 1) * FW_BYTES) + w_off;
@@ -211,9 +201,16 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             lds_write_b64_asm(kvb + kv_wr + tg * 512, u32x2{pack_bf16x2(acc[tg][1][0], acc[tg][1][1]), pack_bf16x2(acc[tg][1][2], acc[tg][1][3])});
             lds_write_b64_asm(kvb + 2048 + kv_wr + tg * 512, u32x2{pack_bf16x2(acc[tg][2][0], acc[tg][2][1]), pack_bf16x2(acc[tg][2][2], acc[tg][2][3])});
         }
+        // ONE barrier per head.  Before it every wave waits for its own pieces of the NEXT head's weights (requested a head
+        // ago; younger than them: the 2 output stores of head h-1 -- none with PROJ -- and the 8 bias loads above), so
+        // passing it means: K / V of this head are written, the next head's weights have landed everywhere, and
+        // everyone is done reading this head's weight slot -- which is refilled right away, two heads ahead.
+        if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // both halves of every window have written K, V
-        if constexpr (PROJ) { if (h + 1 == HEADS) dma_wp(1, 1); }       // slot 1 (head 11's weights) is free now: second proj chunk
+        __builtin_amdgcn_s_barrier();
+        if (h + 2 < HEADS) dma_w(h + 2, h & 1);
+        else if constexpr (PROJ) dma_wp(h + 2 - HEADS, h & 1);  // proj chunks 0 and 1 take the place of "heads 12 and 13"
         s16x4 kf[4], vf[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {

@@ -10,7 +10,7 @@ import os
 from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtupscale_hip.so")
+LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
 ABI_VERSION = 3
 
 P = c_void_p

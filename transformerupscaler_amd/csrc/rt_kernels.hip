@@ -9,6 +9,8 @@
 
 namespace {
 
+constexpr float SCALE_LOG2E = 0.25f * 1.44269504088896340736f;      // head_dim^-0.5 * log2(e)
+
 // Two 4-element fragments -> one v_mfma_f32_16x16x32_bf16 operand (twice the rate of the x16 form on gfx950): k index
 // 8g + j <-> element j of the first fragment (j < 4) or j - 4 of the second; both operands of a product use the same map,
 // so any two 16-wide slices of the contracted axis can be paired.
@@ -73,10 +75,17 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
                 const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
+                // scores in the log2 domain: s * (head_dim^-0.5 * log2 e), so the softmax needs v_exp_f32 only (no multiply
+                // per element); keys beyond N exist only in the last key tile
+                if (k0 + 64 <= N) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = k0 + 16 * kt + 4 * g + e;
-                    st[kt][qt][e] = key < N ? s[e] * 0.25f : -INFINITY;        // q * head_dim^-0.5
+                    for (int e = 0; e < 4; ++e) st[kt][qt][e] = s[e] * SCALE_LOG2E;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = k0 + 16 * kt + 4 * g + e;
+                        st[kt][qt][e] = key < N ? s[e] * SCALE_LOG2E : -INFINITY;
+                    }
                 }
             }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
                 for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[kt][qt][e]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float alpha = __expf(mrun[qt] - mx);             // 0 on the first tile (mrun = -inf)
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mx);        // 0 on the first tile (mrun = -inf)
             float sum = 0.f;
             f32x4 o = oacc[qt];
 #pragma unroll
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
                     const int kt = 2 * kp + hh;
                     float pv[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { pv[e] = __expf(st[kt][qt][e] - mx); sum += pv[e]; }
+                    for (int e = 0; e < 4; ++e) { pv[e] = __builtin_amdgcn_exp2f(st[kt][qt][e] - mx); sum += pv[e]; }
                     if constexpr (DROP) {       // nn.MultiheadAttention drops the normalised probabilities: l keeps the full sum
                         const uint32_t qi = (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + 4 * g);
 #pragma unroll
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
         const float M = fmaxf(fmaxf(comb_m[0][qt][p], comb_m[1][qt][p]), fmaxf(comb_m[2][qt][p], comb_m[3][qt][p]));
-        const float sc = __expf(mrun[qt] - M);             // 0 for a wave that saw no key tile
+        const float sc = __builtin_amdgcn_exp2f(mrun[qt] - M);      // 0 for a wave that saw no key tile
         f32x4 o = oacc[qt];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] *= sc;
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
         }
         const float M = fmaxf(fmaxf(comb_m[0][qt][p], comb_m[1][qt][p]), fmaxf(comb_m[2][qt][p], comb_m[3][qt][p]));
         const float inv = 1.0f / l;
-        if (lse && g == 0) lse[((size_t)b * RH + h) * N + q] = M + __logf(l);     // saved for the backward
+        if (lse && g == 0) lse[((size_t)b * RH + h) * N + q] = (M + __log2f(l)) * 0.69314718055994530942f;     // natural-log LSE, saved for the backward
         bf16_t* op = out + ((size_t)b * N + q) * RD + h * HD + 4 * g;
         *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(o[0] * inv, o[1] * inv), pack_bf16x2(o[2] * inv, o[3] * inv)};
     }

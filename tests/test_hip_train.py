@@ -149,12 +149,14 @@ def test_adam_step_skips_unused_scales(det_sd, golden_dir):
     assert l2 < float(d["loss"]) + 1e-3
 
 
-def test_l1_loss_kernels_match_torch():
+@pytest.mark.parametrize("shape", [(2, 3, 54, 66), (1, 3, 5, 7), (3,)])       # the last two: numel % 4 != 0, < one vector
+def test_l1_loss_kernels_match_torch(shape):
     from transformerupscaler_amd.autograd import l1_loss
     g = torch.Generator().manual_seed(3)
-    a = torch.rand((2, 3, 54, 66), generator=g).cuda().requires_grad_(True)
-    b = torch.rand((2, 3, 54, 66), generator=g).cuda()
-    b.view(-1)[:5] = a.detach().view(-1)[:5]                 # exact ties: sign(0) = 0
+    a = torch.rand(shape, generator=g).cuda().requires_grad_(True)
+    b = torch.rand(shape, generator=g).cuda()
+    b.view(-1)[:2] = a.detach().view(-1)[:2]                 # exact ties: sign(0) = 0
+    b.view(-1)[-1] = a.detach().view(-1)[-1]
     loss = l1_loss(a, b)
     (loss * 3.0).backward()
     a2 = a.detach().clone().requires_grad_(True)
@@ -162,3 +164,5 @@ def test_l1_loss_kernels_match_torch():
     (ref * 3.0).backward()
     assert abs(loss.item() - ref.item()) <= 1e-6
     assert torch.equal(a.grad, a2.grad)
+    with pytest.raises(ValueError):
+        l1_loss(a, b.reshape(1, -1))

@@ -7,9 +7,10 @@
 namespace {
 
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ partial, size_t n4)
+                                                         float* __restrict__ partial, size_t n4, size_t n)
 {
     float acc = 0.f;
+    if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) acc = fabsf(a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x]);   // n % 4 tail
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const f32x4 x = reinterpret_cast<const f32x4*>(a)[i], y = reinterpret_cast<const f32x4*>(b)[i];
@@ -24,9 +25,13 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                     const float* __restrict__ gout, float inv_n, float* __restrict__ ga, size_t n4)
+                                                     const float* __restrict__ gout, float inv_n, float* __restrict__ ga, size_t n4, size_t n)
 {
     const float gs = gout[0] * inv_n;
+    if (blockIdx.x == 0 && n4 * 4 + threadIdx.x < n) {                                                                   // n % 4 tail
+        const float d = a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x];
+        ga[n4 * 4 + threadIdx.x] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+    }
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const f32x4 x = reinterpret_cast<const f32x4*>(a)[i], y = reinterpret_cast<const f32x4*>(b)[i];
@@ -39,13 +44,13 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ a
 
 }  // namespace
 
-// partial[nblocks] = per-workgroup sums of |a - b| over n fp32 elements (n % 4 == 0); the caller adds them (in fp64) and
+// partial[nblocks] = per-workgroup sums of |a - b| over n fp32 elements (any n; 16-byte aligned pointers); the caller adds them (in fp64) and
 // divides by n.  nblocks <= 65535.
 extern "C" int tup_l1_loss_partial(const float* a, const float* b, float* partial, long long n, int nblocks, void* stream)
 {
     if (n <= 0) return 0;
-    if (n % 4 != 0 || nblocks < 1 || nblocks > 65535) return (int)hipErrorInvalidValue;
-    l1_partial_kernel<<<dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, partial, (size_t)(n / 4));
+    if (nblocks < 1 || nblocks > 65535) return (int)hipErrorInvalidValue;
+    l1_partial_kernel<<<dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, partial, (size_t)(n / 4), (size_t)n);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -54,10 +59,10 @@ extern "C" int tup_l1_loss_partial(const float* a, const float* b, float* partia
 extern "C" int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga, long long n, void* stream)
 {
     if (n <= 0) return 0;
-    if (n % 4 != 0) return (int)hipErrorInvalidValue;
     long long blocks = (n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
     if (blocks > 8192) blocks = 8192;
-    l1_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, gout, (float)(1.0 / (double)n), ga, (size_t)(n / 4));
+    l1_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(a, b, gout, (float)(1.0 / (double)n), ga, (size_t)(n / 4), (size_t)n);
     TUP_CHECK_LAUNCH();
     return 0;
 }

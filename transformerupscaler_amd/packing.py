@@ -106,11 +106,14 @@ def compose_branch_a(wu: torch.Tensor, bu: torch.Tensor, w3: torch.Tensor, r: in
     Returns (wc [3*r*r][5][5][64] with output n = c*r*r + si*r + sj and LR taps at offsets -2..2, bc [3*r*r]).
     rowmode/colmode 1 (2) drop the HR taps above (below) / left (right) of the output pixel: the variants
     for the first (last) HR row / column, where the reference zero-pads the HR intermediate."""
-    wu5 = wu.float().reshape(64, r, r, 64, 3, 3)          # [ch][si'][sj'][ci][ky][kx]
-    bu3 = bu.float().reshape(64, r, r)
-    w3 = w3.float()
-    wc = torch.zeros(3, r, r, 5, 5, 64, dtype=torch.float32, device=wu.device)
-    bc = torch.zeros(3, r, r, dtype=torch.float32, device=wu.device)
+    # Composed on the host in fp64 (a one-time weight transform, ~10 ms): no device GEMM library is involved and the
+    # composition error stays far below the bf16 rounding applied afterwards.
+    dev = wu.device
+    wu5 = wu.detach().double().cpu().reshape(64, r, r, 64, 3, 3)          # [ch][si'][sj'][ci][ky][kx]
+    bu3 = bu.detach().double().cpu().reshape(64, r, r)
+    w3 = w3.detach().double().cpu()
+    wc = torch.zeros(3, r, r, 5, 5, 64, dtype=torch.float64)
+    bc = torch.zeros(3, r, r, dtype=torch.float64)
     for si in range(r):
         for dy in range(3):
             if (rowmode == 1 and dy == 0) or (rowmode == 2 and dy == 2):
@@ -121,9 +124,11 @@ def compose_branch_a(wu: torch.Tensor, bu: torch.Tensor, w3: torch.Tensor, r: in
                     if (colmode == 1 and dx == 0) or (colmode == 2 and dx == 2):
                         continue
                     ox, sj2 = divmod(sj + dx - 1, r)
-                    m = torch.einsum("ch,hikl->cikl", w3[:, :, dy, dx], wu5[:, si2, sj2])     # [3][ci][ky][kx]
-                    wc[:, si, sj, oy + 1:oy + 4, ox + 1:ox + 4, :] += m.permute(0, 2, 3, 1)
-                    bc[:, si, sj] += w3[:, :, dy, dx] @ bu3[:, si2, sj2]
+                    m = (w3[:, :, dy, dx].reshape(3, 64, 1) * wu5[:, si2, sj2].reshape(1, 64, 64 * 9)).sum(1)   # [3][ci*ky*kx]
+                    wc[:, si, sj, oy + 1:oy + 4, ox + 1:ox + 4, :] += m.reshape(3, 64, 3, 3).permute(0, 2, 3, 1)
+                    bc[:, si, sj] += (w3[:, :, dy, dx] * bu3[:, si2, sj2].reshape(1, 64)).sum(1)
+    wc = wc.float().to(dev)
+    bc = bc.float().to(dev)
     return wc.reshape(3 * r * r, 5, 5, 64), bc.reshape(3 * r * r)
 
 

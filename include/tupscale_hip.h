@@ -114,8 +114,8 @@ int tup_ln_gemm_fwd(const float* x, const float* gamma, const float* beta, const
                     const float* bias, void* out, int M, int N, void* stream);
 
 /* Inference fusion of the MLP half of a block: x += mlp.2(GELU(mlp.0(norm2(x)))) (model.py:144-151,168-171);
- * the [M][768] hidden tensor stays in LDS.  x fp32 [M][192] in place; w1 bf16 [768][192], w2 bf16 [192][768]
- * (rows permuted per 64-group). */
+ * the [M][768] hidden tensor stays in registers.  x fp32 [M][192] in place; w1 bf16 [768][192] (rows permuted per
+ * 64-group AND columns in the kernel's K order, packing.pack_fc1_fused), w2 bf16 [192][768] (rows permuted per 64-group). */
 int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                       const void* w2, const float* b2, int M, void* stream);
 

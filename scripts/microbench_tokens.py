@@ -17,12 +17,14 @@ M = 8 * 240 * 64
 dev = "cuda"
 x = torch.randn((M, 192), device=dev)
 gm, bt = torch.ones(192, device=dev), torch.zeros(192, device=dev)
-w1, b1 = packing.pack_linear(torch.randn(768, 192) * 0.05).to(dev), torch.zeros(768, device=dev)
+w1raw = torch.randn(768, 192) * 0.05
+w1, b1 = packing.pack_linear(w1raw).to(dev), torch.zeros(768, device=dev)
+w1f = packing.pack_fc1_fused(w1raw).to(dev)
 w2, b2 = packing.pack_linear(torch.randn(192, 768) * 0.05).to(dev), torch.zeros(192, device=dev)
 wq, bq = packing.pack_linear(torch.randn(576, 192) * 0.05).to(dev), torch.zeros(576, device=dev)
 wp, bp = packing.pack_linear(torch.randn(192, 192) * 0.05).to(dev), torch.zeros(192, device=dev)
 frag = ops.relpos_bias_expand(torch.zeros(225, 12, device=dev))
-print("fused_mlp   %.1f us" % timeit(lambda: ops.fused_mlp(x, gm, bt, w1, b1, w2, b2)))
+print("fused_mlp   %.1f us" % timeit(lambda: ops.fused_mlp(x, gm, bt, w1f, b1, w2, b2)))
 def unfused_mlp():
     y = ops.layernorm(x, gm, bt); h = ops.gemm_tokens(y, w1, b1, "gelu"); ops.gemm_tokens(h, w2, b2, "res", res=x, out=x)
 print("unfused_mlp %.1f us" % timeit(unfused_mlp))

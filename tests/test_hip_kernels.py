@@ -401,7 +401,7 @@ def test_fused_mlp(dev, M):
     y = bf(F.layer_norm(x, (192,), gm, bt, 1e-5))
     ref = x + F.linear(bf(F.gelu(F.linear(y, bf(w1), b1))), bf(w2), b2)
     w1p, w2p = packing.pack_linear(w1).to(dev), packing.pack_linear(w2).to(dev)
-    got = ops.fused_mlp(x.to(dev).clone(), gm.to(dev), bt.to(dev), w1p, b1.to(dev), w2p, b2.to(dev))
+    got = ops.fused_mlp(x.to(dev).clone(), gm.to(dev), bt.to(dev), packing.pack_fc1_fused(w1).to(dev), b1.to(dev), w2p, b2.to(dev))
     close(got, ref, 2e-2, 1e-2, "fused mlp vs torch")
     xu = x.to(dev).clone()
     yl = ops.layernorm(xu, gm.to(dev), bt.to(dev))

@@ -3,244 +3,20 @@
 //
 //   tup_fused_mlp_fwd    x += mlp.2(GELU(mlp.0(LayerNorm2(x))))        models/FastTransformer/model.py:144-151,168-171
 //
-// One workgroup = 8 waves (two per SIMD, so one wave's LDS / barrier waits hide under the other's MFMAs)
-// = 256 token rows, 32 per wave.  LN2(x) is built once in LDS (bf16, 48 KB) and is the MFMA
-// token operand of all 12 hidden chunks; per chunk of 64 hidden units the 24 KB slice of W1 and the 24 KB
-// slice of W2 are streamed global -> registers -> LDS (prefetched one chunk ahead); FC1's accumulators,
-// after bias + erf-GELU, ARE the token operand of the FC2 partial product (the lane already holds the 16
-// hidden units its MFMA lane group contracts over), accumulated in 96 registers per lane.  MFMA convention as everywhere: A operand = weight rows, B operand = token rows.
+// FC1's accumulators, after bias + erf-GELU, ARE the token operand of the FC2 partial product (the lane already holds
+// the 16 hidden units its MFMA lane group contracts over), accumulated in 96 registers per lane.  MFMA convention as
+// everywhere: A operand = weight rows, B operand = token rows.
 #include "common.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int DIM = 192, HID = 768, BM = 256;
-constexpr int A_BYTES = 3 * BM * 128;          // LN(x) as three [256][64] swizzled sub-tiles (96 KB)
+constexpr int DIM = 192, HID = 768;
 constexpr int W1_BYTES = 3 * 64 * 128;         // W1 chunk: [64 hidden rows] x 3 k-tiles of 64
 constexpr int W2_BYTES = 3 * 64 * 128;         // W2 chunk: 3 n-tiles of [64 out rows][64 k]
 
-__global__ __launch_bounds__(512, 2) void fused_mlp_kernel(
-    float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const bf16_t* __restrict__ w1, const float* __restrict__ b1, const bf16_t* __restrict__ w2,
-    const float* __restrict__ b2, int M)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* a_lds = smem;
-    char* w1_lds = smem + A_BYTES;
-    char* w2_lds = w1_lds + W1_BYTES;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, pl = lane & 15;
-    const int m0 = blockIdx.x * BM;
-
-    // ---- weight chunk prefetch: W1 rows j*64.. (64 x 192), W2 columns j*64.. of all 192 rows ----
-    u32x4 wreg[6];
-    auto load_w = [&](int j) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int idx = tid + u * 512;               // 1536 chunks: row = idx / 24, c24 = idx % 24
-            const int row = idx / 24, c = idx - row * 24;
-            wreg[u] = *reinterpret_cast<const u32x4*>(w1 + (size_t)(j * 64 + row) * DIM + c * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int idx = tid + u * 512;               // 1536 chunks: row = idx / 8 (0..191), c = idx % 8
-            const int row = idx >> 3, c = idx & 7;
-            wreg[3 + u] = *reinterpret_cast<const u32x4*>(w2 + (size_t)row * HID + j * 64 + c * 8);
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int idx = tid + u * 512;
-            const int row = idx / 24, c = idx - row * 24;
-            *reinterpret_cast<u32x4*>(w1_lds + (c >> 3) * (64 * 128) + swz128(row, c & 7)) = wreg[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int idx = tid + u * 512;
-            const int row = idx >> 3, c = idx & 7;
-            *reinterpret_cast<u32x4*>(w2_lds + (row >> 6) * (64 * 128) + swz128(row & 63, c)) = wreg[3 + u];
-        }
-    };
-    load_w(0);
-
-    // ---- LayerNorm2 prologue: 16 lanes per row, 32 rows per pass ----
-    {
-        const int sub = tid & 15;
-        f32x4 gm[3], bt[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            gm[q] = *reinterpret_cast<const f32x4*>(gamma + q * 64 + sub * 4);
-            bt[q] = *reinterpret_cast<const f32x4*>(beta + q * 64 + sub * 4);
-        }
-#pragma unroll 2
-        for (int pass = 0; pass < BM / 32; ++pass) {
-            const int r = pass * 32 + (tid >> 4);
-            const int m = min(m0 + r, M - 1);
-            f32x4 v[3];
-            float sum = 0.f;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                v[q] = *reinterpret_cast<const f32x4*>(x + (size_t)m * DIM + q * 64 + sub * 4);
-                sum += v[q][0] + v[q][1] + v[q][2] + v[q][3];
-            }
-#pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * (1.0f / DIM);
-            float ss = 0.f;
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[q][e] - mean; ss += d * d; }
-#pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
-            const float rstd = rsqrtf(ss * (1.0f / DIM) + 1e-5f);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                float o4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (v[q][e] - mean) * rstd * gm[q][e] + bt[q][e];
-                *reinterpret_cast<u32x2*>(a_lds + q * (BM * 128) + swz128(r, sub >> 1) + (sub & 1) * 8) =
-                    u32x2{pack_bf16x2(o4[0], o4[1]), pack_bf16x2(o4[2], o4[3])};
-            }
-        }
-    }
-
-    // loop-invariant LDS byte addresses of this lane's fragments
-    //   FC1: token rows 32*wave + 16*tg + pl, k-chunk kh*4+g of sub-tile kc; weight row ct*16+pl (kh = 1 is "^ 64")
-    //   FC2: the token operand never touches LDS (see below); weight row n*16+pl, k-chunk 2g+s
-    const uint32_t a_tok0 = lds_addr(a_lds) + (uint32_t)swz128(32 * wave + pl, g);
-    const uint32_t a_tok1 = lds_addr(a_lds) + (uint32_t)swz128(32 * wave + 16 + pl, g);
-    const uint32_t w1_frag = lds_addr(w1_lds) + (uint32_t)swz128(pl, g);
-    const uint32_t w2_frag0 = lds_addr(w2_lds) + (uint32_t)swz128(pl, 2 * g);
-    const uint32_t w2_frag1 = lds_addr(w2_lds) + (uint32_t)swz128(pl, 2 * g + 1);
-
-    f32x4 acc2[2][12];
-#pragma unroll
-    for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-        for (int n = 0; n < 12; ++n) acc2[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int j = 0; j < HID / 64; ++j) {
-        store_w();
-        __syncthreads();                       // W chunk j (and, first time, the LN tile) visible
-        if (j + 1 < HID / 64) load_w(j + 1);
-
-        // ---- FC1 chunk: [256][64] = LN(x) [256][192] . W1_j^T : 6 K-steps of (2 token + 4 weight) fragments
-        // and 8 MFMAs, fragments of step k+1 requested before the MFMAs of step k (common.h) ----
-        f32x4 acc1[2][4];
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc1[tg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 w2f[12];
-        {
-            bf16x8 tf[2][2], wf[2][4];
-            auto ld1 = [&](int step, int slot) {
-                const int kc = step >> 1;
-                const uint32_t khx = (step & 1) << 6;
-                tf[slot][0] = lds_read_b128_asm((a_tok0 ^ khx) + kc * (BM * 128));
-                tf[slot][1] = lds_read_b128_asm((a_tok1 ^ khx) + kc * (BM * 128));
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) wf[slot][ct] = lds_read_b128_asm((w1_frag ^ khx) + kc * (64 * 128) + ct * 2048);
-            };
-            ld1(0, 0);
-#pragma unroll
-            for (int step = 0; step < 6; ++step) {
-                const int cur = step & 1;
-                if (step + 1 < 6) {
-                    ld1(step + 1, cur ^ 1);
-                    lds_wait<6>();
-                } else {
-                    lds_wait<0>();
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) acc1[tg][ct] = mfma16x16x32(wf[cur][ct], tf[cur][tg], acc1[tg][ct]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-
-        // ---- bias + erf-GELU in registers.  The lane holds hidden units 16g .. 16g+15 of its token (weight rows
-        // are permuted that way), i.e. exactly two 8-wide k-groups: FC2 is run with the K order "lane group g <->
-        // hidden 16g + 8s + j" (s = 0, 1), so its token operand is this lane's own packed values and its weight
-        // fragment is k-chunk 2g+s of W2 -- the hidden tile is never written anywhere. ----
-        // FC2's first 12 weight fragments are requested now and land under the GELU math
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < 12; ++n) w2f[n] = lds_read_b128_asm(w2_frag0 + (n >> 2) * (64 * 128) + (n & 3) * 2048);
-        __builtin_amdgcn_sched_barrier(0);
-        bf16x8 hf[2][2];
-        {
-            f32x4 bb[4];
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) bb[ct] = *reinterpret_cast<const f32x4*>(b1 + j * 64 + g * 16 + ct * 4);
-#pragma unroll
-            for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    u32x4 pk;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int ct = 2 * s + h;
-                        const f32x2 g0 = gelu_erf2(f32x2{acc1[tg][ct][0] + bb[ct][0], acc1[tg][ct][1] + bb[ct][1]});
-                        const f32x2 g1 = gelu_erf2(f32x2{acc1[tg][ct][2] + bb[ct][2], acc1[tg][ct][3] + bb[ct][3]});
-                        pk[2 * h + 0] = pack_bf16x2(g0[0], g0[1]);
-                        pk[2 * h + 1] = pack_bf16x2(g1[0], g1[1]);
-                    }
-                    hf[tg][s] = __builtin_bit_cast(bf16x8, pk);
-                }
-        }
-
-        // ---- FC2 partial: [256][192] += hidden [256][64] . W2[:, chunk j]^T : 2 K-steps x 24 MFMAs ----
-        {
-            __builtin_amdgcn_sched_barrier(0);
-            lds_wait<0>();                     // step 0 fragments (requested before the GELU) have landed
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < 12; ++n)
-#pragma unroll
-                for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32(w2f[n], hf[tg][0], acc2[tg][n]);
-            __builtin_amdgcn_sched_barrier(0);
-            // step 1 reuses the fragment registers: the MFMAs above have issued (operands are read at issue),
-            // the reads below return tens of cycles later
-#pragma unroll
-            for (int n = 0; n < 12; ++n) w2f[n] = lds_read_b128_asm(w2_frag1 + (n >> 2) * (64 * 128) + (n & 3) * 2048);
-            lds_wait<0>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int n = 0; n < 12; ++n)
-#pragma unroll
-                for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32(w2f[n], hf[tg][1], acc2[tg][n]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                       // everyone done with W chunk j before it is overwritten
-    }
-
-    // ---- epilogue: x = x + acc2 + b2 (lane holds features nt*64 + g*16 + ct*4 + e) ----
-#pragma unroll
-    for (int tg = 0; tg < 2; ++tg) {
-        const int m = m0 + 32 * wave + 16 * tg + pl;
-        if (m >= M) continue;
-#pragma unroll
-        for (int n = 0; n < 12; ++n) {
-            const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;
-            float* xp = x + (size_t)m * DIM + col;
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(xp);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + col);
-            f32x4 ov;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = acc2[tg][n][e] + bv[e] + rv[e];
-            *reinterpret_cast<f32x4*>(xp) = ov;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// v2: the token operand never touches LDS.  Each lane loads its rows of x directly in MFMA B-fragment order
+// The token operand never touches LDS.  Each lane loads its rows of x directly in MFMA B-fragment order
 // (token 16tg+pl, channels 32*step + 8g .. +8), LayerNorm statistics are two cross-lane-group shuffles, and the
 // 12 bf16x8 fragments of LN2(x) stay in registers for all 12 hidden chunks.  LDS holds only the weight stream,
 // filled by LDS-DMA (global_load_lds_dwordx4, swizzle applied on the source side): W1 chunks double-buffered (the
@@ -286,13 +62,15 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
     const int drow = tid >> 3, dc = (tid & 7) ^ ((tid >> 4) & 7);
     const bf16_t* w1_thr = w1 + (size_t)drow * DIM + dc * 8;
     const bf16_t* w2_thr = w2 + (size_t)drow * HID + dc * 8;
-    auto dma_w1 = [&](int j, int buf) {
+    auto dma_w1_piece = [&](int j, int buf, int u) {
         char* dst = smem + buf * W1_BYTES + wave * 1024;
         const bf16_t* src = w1_thr + (size_t)j * 64 * DIM;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
+                                         (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+    };
+    auto dma_w1 = [&](int j, int buf) {
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+        for (int u = 0; u < 6; ++u) dma_w1_piece(j, buf, u);
     };
     auto dma_w2 = [&](int j) {
         char* dst = smem + V2_W2_OFF + wave * 1024;
@@ -304,19 +82,25 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
     };
     dma_w1(0, 0);
 
-    // ---- LayerNorm2 straight into B fragments ----
+    // ---- LayerNorm2 straight into B fragments, residual straight into the FC2 accumulators ----
+    // K-step st of FC1 contracts, in lane group g, over channels 64*(st>>1) + 16g + 8*(st&1) .. +8 (the columns of the
+    // packed W1 are permuted to match, packing.pack_fc1_fused): these are exactly the features this lane's FC2
+    // accumulators n = 2*st, 2*st+1 hold, so acc2 starts as x + b2 and the epilogue is a plain store -- the residual is
+    // read once, not twice.
     bf16x8 tf[2][6];
+    f32x4 acc2[2][12];
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
         const int m = min(m0 + 32 * wave + 16 * tg + pl, M - 1);
-        const float* xr = x + (size_t)m * DIM + 8 * g;
+        const float* xr = x + (size_t)m * DIM + 16 * g;
         f32x4 v[6][2];
         float sum = 0.f;
 #pragma unroll
         for (int st = 0; st < 6; ++st) {
+            const int c0 = 64 * (st >> 1) + 8 * (st & 1);
             if constexpr ((ABL & 16) != 0) { v[st][0] = f32x4{1.f * st, 2.f, 3.f, 4.f + g}; v[st][1] = f32x4{0.5f, 1.f * pl, 3.f, 4.f}; continue; }
-            v[st][0] = *reinterpret_cast<const f32x4*>(xr + 32 * st);
-            v[st][1] = *reinterpret_cast<const f32x4*>(xr + 32 * st + 4);
+            v[st][0] = *reinterpret_cast<const f32x4*>(xr + c0);
+            v[st][1] = *reinterpret_cast<const f32x4*>(xr + c0 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) sum += v[st][0][e] + v[st][1][e];
         }
@@ -338,25 +122,22 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             uint32_t pk[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 32 * st + 8 * g + 4 * h);
-                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 32 * st + 8 * g + 4 * h);
+                const int c = 64 * (st >> 1) + 16 * g + 8 * (st & 1) + 4 * h;
+                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + c);
                 float o4[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o4[e] = (v[st][h][e] - mean) * rstd * gm[e] + bt[e];
                 pk[2 * h] = pack_bf16x2(o4[0], o4[1]);
                 pk[2 * h + 1] = pack_bf16x2(o4[2], o4[3]);
+                acc2[tg][2 * st + h] = v[st][h] + bv;
             }
             tf[tg][st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
         }
     }
 
     stamp();                   // 1: prologue done
-    f32x4 acc2[2][12];
-#pragma unroll
-    for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-        for (int n = 0; n < 12; ++n) acc2[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     const uint32_t sbase = lds_addr(smem);
     const uint32_t w1_off = (uint32_t)swz128(pl, g);
     const uint32_t w2_off0 = (uint32_t)(V2_W2_OFF + swz128(pl, 2 * g)), w2_off1 = (uint32_t)(V2_W2_OFF + swz128(pl, 2 * g + 1));
@@ -368,10 +149,10 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
         if (j < 3) stamp();        // after own vmcnt
         __syncthreads();                                       // everyone's have; everyone is done with chunk j-1 (W2 buffer free)
         if (j < 3) stamp();        // after barrier
-        if ((ABL & 8) == 0 || j == 0) {
-            dma_w2(j);
-            if (j + 1 < HID / 64) dma_w1(j + 1, (j + 1) & 1);
-        }
+        // W2 chunk j now (needed first); the six pieces of W1 chunk j+1 are issued one per K-step of the first FC1 half
+        // below, in the shadow of its MFMAs (issued in a block here they held the wave for ~60 cycles each, stamped)
+        dma_w2(j);
+        const bool more = j + 1 < HID / 64;
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t wb1 = sbase + (uint32_t)((j & 1) * W1_BYTES);
 
@@ -409,12 +190,17 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
                     for (int h = 0; h < 2; ++h)
                         if ((ABL & 2) == 0 || step == 0) acc1[tg][h] = mfma16x16x32(wf[cur][h], tf[tg][step], acc1[tg][h]);
                 __builtin_amdgcn_sched_barrier(0);
+                if (s == 0 && more) { dma_w1_piece(j + 1, (j + 1) & 1, step); __builtin_amdgcn_sched_barrier(0); }
             }
             if (j < 3) stamp();    // FC1 half done
             // ---- FC2 weight fragments (first 6 n tiles) land under the GELU math ----
             if (s == 0) {          // W2 chunk j was requested at the top of the chunk: own pieces, then everyone's
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           // all but the youngest 6 (= the W1 prefetch) have landed
-                __syncthreads();
+                // all but the youngest 6 (= the W1 prefetch, if any) have landed; raw barrier: __syncthreads() would make
+                // hipcc wait vmcnt(0), i.e. for the W1 pieces issued a moment ago
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
                 if (j < 3) stamp();    // W2 barrier passed
             }
             // FC2 weight fragments: 8 of the 12 are requested now and land under the GELU math (with 2 MFMAs per
@@ -473,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
     }
 
     stamp();                   // loop done
-    // ---- epilogue: x = x + acc2 + b2 (lane holds features nt*64 + g*16 + ct*4 + e) ----
+    // ---- epilogue: acc2 already holds x + b2 + FC2 (lane holds features (n>>2)*64 + g*16 + (n&3)*4 + e) ----
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
         const int m = m0 + 32 * wave + 16 * tg + pl;
@@ -483,12 +269,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;
             float* xp = x + (size_t)m * DIM + col;
             if constexpr ((ABL & 32) != 0) { if (acc2[tg][n][0] == 123.456f) *xp = 1.f; continue; }
-            const f32x4 rv = *reinterpret_cast<const f32x4*>(xp);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + col);
-            f32x4 ov;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ov[e] = acc2[tg][n][e] + bv[e] + rv[e];
-            *reinterpret_cast<f32x4*>(xp) = ov;
+            *reinterpret_cast<f32x4*>(xp) = acc2[tg][n];
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -503,8 +284,7 @@ extern "C" int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta
                                  const void* w2, const float* b2, int M, void* stream)
 {
     if (M <= 0) return 0;
-    static const bool use_v1 = (getenv("TUP_MLP_V1") != nullptr);
-    if (!use_v1) {
+    {
         constexpr size_t lds2 = V2_LDS;
         static bool attr2_set = false;
         if (!attr2_set) {
@@ -516,7 +296,7 @@ extern "C" int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const char* abl = getenv("TUP_MLP_ABLATE");            // timing experiments only (results are wrong)
         if (abl) {
-#define TUP_ABL_CASE(V) case V: { hipFuncSetAttribute((const void*)fused_mlp_v2_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+#define TUP_ABL_CASE(V) case V: { (void)hipFuncSetAttribute((const void*)fused_mlp_v2_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
             fused_mlp_v2_kernel<V><<<grid, dim3(256), lds2, st>>>(x, gamma, beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, M); break; }
             switch (atoi(abl)) { TUP_ABL_CASE(1) TUP_ABL_CASE(6) TUP_ABL_CASE(7) TUP_ABL_CASE(48) TUP_ABL_CASE(55) TUP_ABL_CASE(64) default: return (int)hipErrorInvalidValue; }
 #undef TUP_ABL_CASE
@@ -527,17 +307,6 @@ extern "C" int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta
         TUP_CHECK_LAUNCH();
         return 0;
     }
-    constexpr size_t lds = A_BYTES + W1_BYTES + W2_BYTES;      // 144 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    fused_mlp_kernel<<<dim3((M + BM - 1) / BM), dim3(512), lds, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma, beta, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2, M);
-    TUP_CHECK_LAUNCH();
-    return 0;
 }
 
 // Timing experiments only: copies the s_memtime stamps of the last TUP_MLP_ABLATE=64 launch (4 workgroups x 64).

@@ -59,7 +59,7 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
             # the whole attention half in one kernel, in place: neither the qkv nor the attention-output tensor exists
             ops.fused_attn_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
                                  pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"])
-            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"],
+            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"],
                           pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
             continue
         if fuse_blocks and fuse_attention and capture is None and f"b{i}.qkv.wh" in pk:
@@ -73,8 +73,8 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
                 qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
             att = ops.window_attn(qkv, bias_frags[i])
         ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=x, out=x)
-        if fuse_blocks:
-            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"],
+        if fuse_blocks and f"b{i}.fc1.wf" in pk:
+            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"],
                           pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
         else:
             y = ops.layernorm(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"])

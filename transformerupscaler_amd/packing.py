@@ -65,6 +65,16 @@ def pack_linear(weight: torch.Tensor):
     return perm_rows64(weight).contiguous().to(torch.bfloat16)
 
 
+def pack_fc1_fused(weight: torch.Tensor):
+    """mlp.0 weight for tup_fused_mlp_fwd: pack_linear plus a column permutation.  K-step st of the kernel's FC1, lane
+    group g, element j contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j -- the channels whose residual the same
+    lane carries in its FC2 accumulators -- so packed column 32st + 8g + j holds that channel."""
+    k = torch.arange(192)
+    st, g, j = k // 32, (k % 32) // 8, k % 8
+    src = 64 * (st // 2) + 16 * g + 8 * (st % 2) + j
+    return pack_linear(weight)[:, src.to(weight.device)].contiguous()
+
+
 def pack_qkv_heads(weight: torch.Tensor, bias: torch.Tensor, heads: int = 12):
     """attn.qkv Linear [3*dim][dim] -> per head the 16 q, 16 k, 16 v weight rows in natural channel order + 16 zero rows:
     bf16 [heads][64][dim], and the matching biases fp32 [heads][48] (tup_fused_qkv_attn_fwd)."""
@@ -205,6 +215,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         for i in range(BLOCKS):
             pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"window_blocks.{i}.attn.qkv.weight"], sd[f"window_blocks.{i}.attn.qkv.bias"])
             pk[f"b{i}.proj.wpp"] = pack_proj_pairs(sd[f"window_blocks.{i}.attn.proj.weight"])
+            pk[f"b{i}.fc1.wf"] = pack_fc1_fused(sd[f"window_blocks.{i}.mlp.0.weight"].detach())
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
     pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])

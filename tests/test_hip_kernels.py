@@ -410,6 +410,30 @@ def test_fused_mlp(dev, M):
     close(got, xu, 2e-3, 1e-3, "fused mlp vs unfused kernels")
 
 
+@pytest.mark.parametrize("B,H,W,r,out_hw", [(2, 40, 72, 2, (60, 108)), (1, 37, 53, 2, (74, 106)), (1, 37, 53, 2, (55, 80)),
+                                           (1, 24, 40, 3, (54, 90)), (1, 16, 20, 6, (70, 100)), (1, 90, 150, 2, (135, 225))])
+def test_tail_fused_vs_unfused(dev, B, H, W, r, out_hw):
+    """tup_tail_fused_fwd (last final_upscale stage + final_upscale_conv + "+ upscaled_input" + antialiased Resize +
+    clamp, model.py:316-327) against the one-kernel-per-op HIP path: all fp32, so they agree to rounding."""
+    from transformerupscaler_amd import ops, packing
+    x = rnd((B, 3, H, W), 90, 0.4, 0.3).to(dev)
+    wfu = packing.pack_planar(rnd((3 * r * r, 3, 3, 3), 91, 0.2)).to(dev)
+    bfu = rnd((3 * r * r,), 92, 0.1).to(dev)
+    wfc = packing.pack_planar(rnd((3, 3, 3, 3), 93, 0.2)).to(dev)
+    bfc = rnd((3,), 94, 0.1).to(dev)
+    ui = rnd((B, 3, H * r, W * r), 95, 0.3, 0.4).to(dev)
+    got = ops.tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True)
+    t1 = ops.conv_planar(x, wfu, bfu, r)
+    same = tuple(out_hw) == (H * r, W * r)
+    ref = ops.conv_planar(t1, wfc, bfc, 1, add=ui, clamp=same)
+    if not same:
+        ref = ops.resize_aa(ref, out_hw, clamp=True)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-5, err
+    assert 0.05 < ref.mean().item() < 0.95          # the clamp is not saturating the comparison away
+
+
 def test_ln_gemm_fused(dev):
     from transformerupscaler_amd import ops, packing
     M, N = 448, 576

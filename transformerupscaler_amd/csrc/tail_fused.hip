@@ -28,14 +28,18 @@ struct TailParams {
     int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01, stamps;
 };
 
-template <int OCC>
+// STAMPS is a build variant, not a run-time flag: a (conditional) global store ahead of the weight loads makes hipcc
+// treat global memory as clobbered and fetch the wave-uniform weights with vector loads into VGPRs instead of s_load.
+template <int OCC, bool STAMPS>
 __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float fl[];
     int nst = 0;
     auto stamp = [&]() {
-        if (p.stamps && blockIdx.x == 10 && blockIdx.y == 20 && blockIdx.z == 3 && threadIdx.x == 0) tup_tail_stamps[nst] = __builtin_amdgcn_s_memtime();
-        ++nst;
+        if constexpr (STAMPS) {
+            if (blockIdx.x == 10 && blockIdx.y == 20 && blockIdx.z == 3 && threadIdx.x == 0) tup_tail_stamps[nst] = __builtin_amdgcn_s_memtime();
+            ++nst;
+        }
     };
     stamp();
     const int r = p.r, rr = r * r, nfu = 3 * rr;
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 
     for (int i = tid; i < nfu * 28; i += NT) wfu[i] = p.wfu[i];
     for (int i = tid; i < nfu; i += NT) bfu[i] = p.bfu[i];
+    if (tid < 84) wfc[tid] = p.wfc[tid];
     // ---- stage A: LR window (zero outside the image = the conv's zero padding) ----
     // (all tile loops below are 2-D with power-of-two thread strides: runtime integer divisions cost ~40
     //  instructions each and used to outweigh the arithmetic)
@@ -102,72 +107,101 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
     __syncthreads();
     stamp();          // 3: t1 zeroed
     {
-        const int nslots = NT / rr;
-        const int ph = tid % rr, slot = tid / rr;
-        if (slot < nslots) {
+        // A WAVE owns one sub-pixel phase (si, sj) at a time, so its 81 weights are wave-uniform (all 81 as scalar
+        // operands need 81 + ~25 SGPRs: hipcc then spills SGPRs to VGPR lanes and pays a v_readlane per FMA; all 81 in
+        // VGPRs push the loop past the 128 registers of two workgroups per CU -- hence the split below).  The 64 lanes
+        // walk the LR pixels of the window two at a time: the 3x4 taps of a (ci, ky) row give the pairs (v0,v1),
+        // (v1,v2), (v2,v3), so every weight is one v_pk_fma_f32 (weight broadcast through op_sel) for two pixels.
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lplane = p.LH * p.LW;
+        const int Ya = max(hy0 - 1, 0), Yb = min(hy0 + eh, Hs - 1), Xa = max(hx0 - 1, 0), Xb = min(hx0 + ew, Ws - 1);
+        for (int ph = wv; ph < rr; ph += NROW) {
             const int si = ph / r, sj = ph - si * r;
-            float w[3][27], bias3[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                bias3[c] = bfu[c * rr + ph];
-#pragma unroll
-                for (int k = 0; k < 27; ++k) w[c][k] = wfu[(c * rr + ph) * 28 + k];
-            }
             // LR pixels whose phase-(si,sj) child lies in the t1 window [hy0-1, hy0+eh] x [hx0-1, hx0+ew] and the image
-            const int Ya = max(hy0 - 1, 0), Yb = min(hy0 + eh, Hs - 1), Xa = max(hx0 - 1, 0), Xb = min(hx0 + ew, Ws - 1);
             const int ya = (Ya - si + r - 1) / r, yb = (Yb - si >= 0) ? (Yb - si) / r : -1;
             const int xa = (Xa - sj + r - 1) / r, xb = (Xb - sj >= 0) ? (Xb - sj) / r : -1;
-            const int scols = nslots >= 16 ? 16 : nslots, srows = nslots / scols;
-            const int s_row = slot / scols, s_col = slot - s_row * scols;
-            if (s_row < srows)
-            for (int y = ya + s_row; y <= yb; y += srows)
-            for (int x = xa + s_col; x <= xb; x += scols) {
+            const int npair = (xb - xa + 2) >> 1, nq = (yb - ya + 1) * npair;
+            if (npair <= 0) continue;
+            const float inv_np = 1.0f / (float)npair;
+            // register budget: one output channel's weights as scalar operands (s_load from the kernel argument: the
+            // phase is wave-uniform), the other two channels' in VGPRs (read from the LDS copy) -- 27 SGPRs + 54 VGPRs
+            const float* __restrict__ w0 = p.wfu + ph * 28;
+            float w1[27], w2[27];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) { w1[k] = wfu[(rr + ph) * 28 + k]; w2[k] = wfu[(2 * rr + ph) * 28 + k]; }
+            const float bb0 = bfu[ph], bb1 = bfu[rr + ph], bb2 = bfu[2 * rr + ph];
+            for (int q = t_col; q < nq; q += 64) {
+                const int yr = (int)(((float)q + 0.5f) * inv_np);
+                const int y = ya + yr, x = xa + 2 * (q - yr * npair);
                 const float* base = lr + (y - 1 - ly0) * p.LW + (x - 1 - lx0);
-                float a0 = bias3[0], a1 = bias3[1], a2 = bias3[2];
+                f32x2 a0 = {bb0, bb0}, a1 = {bb1, bb1}, a2 = {bb2, bb2};
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float* rp = base + ci * lplane + ky * p.LW;
+                        const float v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3];
+                        const f32x2 pr[3] = {f32x2{v0, v1}, f32x2{v1, v2}, f32x2{v2, v3}};
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
-                            const float v = base[ci * p.LH * p.LW + ky * p.LW + kx];
                             const int k = ci * 9 + ky * 3 + kx;
-                            a0 = fmaf(w[0][k], v, a0); a1 = fmaf(w[1][k], v, a1); a2 = fmaf(w[2][k], v, a2);
+                            a0 = __builtin_elementwise_fma(f32x2{w0[k], w0[k]}, pr[kx], a0);
+                            a1 = __builtin_elementwise_fma(f32x2{w1[k], w1[k]}, pr[kx], a1);
+                            a2 = __builtin_elementwise_fma(f32x2{w2[k], w2[k]}, pr[kx], a2);
                         }
+                    }
                 const int ty = y * r + si - (hy0 - 1), tx = x * r + sj - (hx0 - 1);
-                t1[0 * TH1 * TW1 + ty * TW1 + tx] = a0;
-                t1[1 * TH1 * TW1 + ty * TW1 + tx] = a1;
-                t1[2 * TH1 * TW1 + ty * TW1 + tx] = a2;
+                float* tp = t1 + ty * TW1 + tx;
+                tp[0] = a0[0]; tp[TH1 * TW1] = a1[0]; tp[2 * TH1 * TW1] = a2[0];
+                if (x + 1 <= xb) { tp[r] = a0[1]; tp[TH1 * TW1 + r] = a1[1]; tp[2 * TH1 * TW1 + r] = a2[1]; }
             }
         }
     }
     stamp();          // 4: stage B done
     __syncthreads();
     stamp();          // 5: barrier
-    // ---- stage C: sum = conv3x3(t1) + bias + upscaled_input on the HR window; the 81 weights are wave-uniform
-    // (scalar loads straight from the kernel argument), the t1 taps come from LDS ----
+    // ---- stage C: sum = conv3x3(t1) + bias + upscaled_input on the HR window; the t1 taps come from LDS ----
     {
-        const float* __restrict__ wg = p.wfc;
+        const float* __restrict__ wg = p.wfc;          // channel 0: scalar operands; channels 1, 2: VGPRs (see stage B)
+        float wg1[27], wg2[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) { wg1[k] = wfc[28 + k]; wg2[k] = wfc[56 + k]; }
         const float b0 = p.bfc[0], b1 = p.bfc[1], b2 = p.bfc[2];
-        for (int sy = t_row; sy < eh; sy += NROW)
-        for (int sx = t_col; sx < ew; sx += 64) {
+        // two adjacent HR pixels per thread (packed FMAs as in stage B); the (row, pair) space is walked flat so that
+        // the 512 threads stay busy whatever the window shape (rows = q / npair through an exact float reciprocal)
+        const int npair = (ew + 1) >> 1, nq = eh * npair;
+        const float inv_np = 1.0f / (float)npair;
+        const size_t cstride = (size_t)Hs * Ws;
+        const int tplane = TH1 * TW1, splane = p.EH * p.EW;
+        for (int q = tid; q < nq; q += NT) {
+            const int sy = (int)(((float)q + 0.5f) * inv_np);
+            const int sx = 2 * (q - sy * npair);
+            const bool two = sx + 1 < ew;
             const int Y = hy0 + sy, X = hx0 + sx;             // always inside the HR image
-            float a0 = b0, a1 = b1, a2 = b2;
+            const size_t o = ((size_t)b * 3 * Hs + Y) * Ws + X;
+            float u[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { u[c][0] = p.ui[o + c * cstride]; u[c][1] = two ? p.ui[o + c * cstride + 1] : 0.f; }
+            f32x2 a0 = {b0, b0}, a1 = {b1, b1}, a2 = {b2, b2};
             const float* base = t1 + sy * TW1 + sx;           // t1 tile origin is (hy0-1, hx0-1)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* rp = base + ci * tplane + ky * TW1;
+                    const float v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3];
+                    const f32x2 pr[3] = {f32x2{v0, v1}, f32x2{v1, v2}, f32x2{v2, v3}};
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float v = base[ci * TH1 * TW1 + ky * TW1 + kx];
                         const int k = ci * 9 + ky * 3 + kx;
-                        a0 = fmaf(wg[k], v, a0); a1 = fmaf(wg[28 + k], v, a1); a2 = fmaf(wg[56 + k], v, a2);
+                        a0 = __builtin_elementwise_fma(f32x2{wg[k], wg[k]}, pr[kx], a0);
+                        a1 = __builtin_elementwise_fma(f32x2{wg1[k], wg1[k]}, pr[kx], a1);
+                        a2 = __builtin_elementwise_fma(f32x2{wg2[k], wg2[k]}, pr[kx], a2);
                     }
-            const size_t o = ((size_t)b * 3 * Hs + Y) * Ws + X;
-            sm[0 * p.EH * p.EW + sy * p.EW + sx] = a0 + p.ui[o];
-            sm[1 * p.EH * p.EW + sy * p.EW + sx] = a1 + p.ui[o + (size_t)Hs * Ws];
-            sm[2 * p.EH * p.EW + sy * p.EW + sx] = a2 + p.ui[o + 2 * (size_t)Hs * Ws];
+                }
+            float* sp = sm + sy * p.EW + sx;
+            sp[0] = a0[0] + u[0][0]; sp[splane] = a1[0] + u[1][0]; sp[2 * splane] = a2[0] + u[2][0];
+            if (two) { sp[1] = a0[1] + u[0][1]; sp[splane + 1] = a1[1] + u[1][1]; sp[2 * splane + 1] = a2[1] + u[2][1]; }
         }
     }
     stamp();          // 6: stage C done
@@ -235,15 +269,14 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, two 512-thread workgroups per CU) or 2
     static const bool occ2 = getenv("TUP_TAIL_OCC2") != nullptr;
     dim3 grid((Wo + OT_W - 1) / OT_W, (Ho + OT_H - 1) / OT_H, B);
-    if (occ2) {
-        hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        tail_fused_kernel<2><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
-    } else {
-        hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        tail_fused_kernel<4><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p);
-    }
+#define TUP_TAIL_LAUNCH(OCC, ST) do { \
+        hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<OCC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e; \
+        tail_fused_kernel<OCC, ST><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p); } while (0)
+    if (stamps_on) TUP_TAIL_LAUNCH(4, true);
+    else if (occ2) TUP_TAIL_LAUNCH(2, false);
+    else TUP_TAIL_LAUNCH(4, false);
+#undef TUP_TAIL_LAUNCH
     TUP_CHECK_LAUNCH();
     return 0;
 }

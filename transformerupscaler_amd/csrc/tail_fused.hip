@@ -28,16 +28,23 @@ struct TailParams {
     int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01, stamps;
 };
 
-// STAMPS is a build variant, not a run-time flag: a (conditional) global store ahead of the weight loads makes hipcc
-// treat global memory as clobbered and fetch the wave-uniform weights with vector loads into VGPRs instead of s_load.
+// STAMPS is a build variant, and the stamps are parked in LDS until the end of the kernel: a (conditional) global store
+// ahead of the weight loads makes hipcc treat global memory as clobbered and fetch the wave-uniform weights with vector
+// loads into VGPRs instead of s_load.
+template <bool S> __device__ unsigned long long* stamp_buf()
+{
+    if constexpr (S) { __shared__ unsigned long long b[16]; return b; } else return nullptr;
+}
+
 template <int OCC, bool STAMPS>
 __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float fl[];
+    unsigned long long* st_lds = stamp_buf<STAMPS>();
     int nst = 0;
     auto stamp = [&]() {
         if constexpr (STAMPS) {
-            if (blockIdx.x == 10 && blockIdx.y == 20 && blockIdx.z == 3 && threadIdx.x == 0) tup_tail_stamps[nst] = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0) st_lds[nst] = __builtin_amdgcn_s_memtime();
             ++nst;
         }
     };
@@ -47,7 +54,8 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
     const int TH1 = p.EH + 2, TW1 = p.EW + 2;            // t1 tile (sum window + 3x3 halo)
     float* wfu = fl;                                    // [nfu][28]
     float* bfu = wfu + nfu * 28;                        // [nfu]
-    float* wfc = bfu + nfu;                             // [3][28] + [3] bias at wfc[84..86]
+    float* wfc = bfu + ((nfu + 1) & ~1);                // [3][28] + [3] bias at wfc[84..86]  (every array starts 8-B aligned,
+                                                        //  every row pitch is even: the pixel-pair reads below are ds_read_b64)
     float* lr = wfc + 88;                               // [3][LH][LW]
     float* t1 = lr + 3 * p.LH * p.LW;                   // [3][TH1][TW1]
     float* sm = t1 + 3 * TH1 * TW1;                     // [3][EH][EW]
@@ -115,13 +123,18 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int lplane = p.LH * p.LW;
         const int Ya = max(hy0 - 1, 0), Yb = min(hy0 + eh, Hs - 1), Xa = max(hx0 - 1, 0), Xb = min(hx0 + ew, Ws - 1);
-        for (int ph = wv; ph < rr; ph += NROW) {
+        // rr < 8 phases (r = 1, 2): NROW / rr waves share a phase and interleave its pixel pairs
+        const int nparts = rr < NROW ? NROW / rr : 1;
+        const int part = wv / rr;                       // 0 when rr >= NROW
+        for (int ph = wv % rr; ph < rr && part < nparts; ph += NROW) {
             const int si = ph / r, sj = ph - si * r;
             // LR pixels whose phase-(si,sj) child lies in the t1 window [hy0-1, hy0+eh] x [hx0-1, hx0+ew] and the image
             const int ya = (Ya - si + r - 1) / r, yb = (Yb - si >= 0) ? (Yb - si) / r : -1;
             const int xa = (Xa - sj + r - 1) / r, xb = (Xb - sj >= 0) ? (Xb - sj) / r : -1;
-            const int npair = (xb - xa + 2) >> 1, nq = (yb - ya + 1) * npair;
-            if (npair <= 0) continue;
+            // pairs start on an even column of the LR tile (8-B aligned, conflict-free ds_read_b64): one pixel early if needed
+            const int x0 = xa - ((xa - 1 - lx0) & 1);
+            const int npair = (xb - x0 + 2) >> 1, nq = (yb - ya + 1) * npair;
+            if (npair <= 0 || yb < ya) continue;
             const float inv_np = 1.0f / (float)npair;
             // register budget: one output channel's weights as scalar operands (s_load from the kernel argument: the
             // phase is wave-uniform), the other two channels' in VGPRs (read from the LDS copy) -- 27 SGPRs + 54 VGPRs
@@ -130,9 +143,9 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 #pragma unroll
             for (int k = 0; k < 27; ++k) { w1[k] = wfu[(rr + ph) * 28 + k]; w2[k] = wfu[(2 * rr + ph) * 28 + k]; }
             const float bb0 = bfu[ph], bb1 = bfu[rr + ph], bb2 = bfu[2 * rr + ph];
-            for (int q = t_col; q < nq; q += 64) {
+            for (int q = part * 64 + t_col; q < nq; q += 64 * nparts) {
                 const int yr = (int)(((float)q + 0.5f) * inv_np);
-                const int y = ya + yr, x = xa + 2 * (q - yr * npair);
+                const int y = ya + yr, x = x0 + 2 * (q - yr * npair);
                 const float* base = lr + (y - 1 - ly0) * p.LW + (x - 1 - lx0);
                 f32x2 a0 = {bb0, bb0}, a1 = {bb1, bb1}, a2 = {bb2, bb2};
 #pragma unroll
@@ -140,8 +153,8 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         const float* rp = base + ci * lplane + ky * p.LW;
-                        const float v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3];
-                        const f32x2 pr[3] = {f32x2{v0, v1}, f32x2{v1, v2}, f32x2{v2, v3}};
+                        const f32x2 lo = *reinterpret_cast<const f32x2*>(rp), hi = *reinterpret_cast<const f32x2*>(rp + 2);
+                        const f32x2 pr[3] = {lo, f32x2{lo[1], hi[0]}, hi};
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
                             const int k = ci * 9 + ky * 3 + kx;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
                     }
                 const int ty = y * r + si - (hy0 - 1), tx = x * r + sj - (hx0 - 1);
                 float* tp = t1 + ty * TW1 + tx;
-                tp[0] = a0[0]; tp[TH1 * TW1] = a1[0]; tp[2 * TH1 * TW1] = a2[0];
+                if (x >= xa) { tp[0] = a0[0]; tp[TH1 * TW1] = a1[0]; tp[2 * TH1 * TW1] = a2[0]; }
                 if (x + 1 <= xb) { tp[r] = a0[1]; tp[TH1 * TW1 + r] = a1[1]; tp[2 * TH1 * TW1 + r] = a2[1]; }
             }
         }
@@ -189,8 +202,8 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const float* rp = base + ci * tplane + ky * TW1;
-                    const float v0 = rp[0], v1 = rp[1], v2 = rp[2], v3 = rp[3];
-                    const f32x2 pr[3] = {f32x2{v0, v1}, f32x2{v1, v2}, f32x2{v2, v3}};
+                    const f32x2 lo = *reinterpret_cast<const f32x2*>(rp), hi = *reinterpret_cast<const f32x2*>(rp + 2);
+                    const f32x2 pr[3] = {lo, f32x2{lo[1], hi[0]}, hi};
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int k = ci * 9 + ky * 3 + kx;
@@ -200,8 +213,13 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
                     }
                 }
             float* sp = sm + sy * p.EW + sx;
-            sp[0] = a0[0] + u[0][0]; sp[splane] = a1[0] + u[1][0]; sp[2 * splane] = a2[0] + u[2][0];
-            if (two) { sp[1] = a0[1] + u[0][1]; sp[splane + 1] = a1[1] + u[1][1]; sp[2 * splane + 1] = a2[1] + u[2][1]; }
+            if (two) {
+                *reinterpret_cast<f32x2*>(sp) = f32x2{a0[0] + u[0][0], a0[1] + u[0][1]};
+                *reinterpret_cast<f32x2*>(sp + splane) = f32x2{a1[0] + u[1][0], a1[1] + u[1][1]};
+                *reinterpret_cast<f32x2*>(sp + 2 * splane) = f32x2{a2[0] + u[2][0], a2[1] + u[2][1]};
+            } else {
+                sp[0] = a0[0] + u[0][0]; sp[splane] = a1[0] + u[1][0]; sp[2 * splane] = a2[0] + u[2][0];
+            }
         }
     }
     stamp();          // 6: stage C done
@@ -241,6 +259,10 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
         }
     }
     stamp();          // 8: stage D done
+    if constexpr (STAMPS) {
+        if (blockIdx.x == 10 && blockIdx.y == 20 && blockIdx.z == 3 && threadIdx.x == 0)
+            for (int i = 0; i < nst; ++i) tup_tail_stamps[i] = st_lds[i];
+    }
 }
 
 }  // namespace
@@ -259,12 +281,13 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     TailParams p{};
     p.x = x; p.wfu = wfu; p.bfu = bfu; p.wfc = wfc; p.bfc = bfc; p.ui = ui; p.out = out;
     p.ymin = ymin; p.ysize = ysize; p.yw = yw; p.KY = KY; p.xmin = xmin; p.xsize = xsize; p.xw = xw; p.KX = KX;
+    EW = (EW + 1) & ~1;                   // even row pitches (see the kernel's LDS layout)
     p.H = H; p.W = W; p.r = r; p.Ho = Ho; p.Wo = Wo; p.EH = EH; p.EW = EW; p.clamp01 = clamp01;
     static const int stamps_on = getenv("TUP_TAIL_STAMPS") ? 1 : 0;
     p.stamps = stamps_on;
-    p.LH = (EH + 2) / r + 4; p.LW = (EW + 2) / r + 4;
+    p.LH = (EH + 2) / r + 4; p.LW = ((EW + 2) / r + 4 + 1) & ~1;
     const int nfu = 3 * r * r;
-    const size_t lds = ((size_t)nfu * 29 + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW) * sizeof(float);
+    const size_t lds = ((size_t)nfu * 28 + ((nfu + 1) & ~1) + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, two 512-thread workgroups per CU) or 2
     static const bool occ2 = getenv("TUP_TAIL_OCC2") != nullptr;

@@ -25,7 +25,7 @@ struct TailParams {
     float* out;                // [B][3][Ho][Wo]
     const int* ymin; const int* ysize; const float* yw; int KY;
     const int* xmin; const int* xsize; const float* xw; int KX;
-    int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01, stamps;
+    int H, W, r, Ho, Wo, EH, EW, LH, LW, clamp01, stamps, abl;
 };
 
 // STAMPS is a build variant, and the stamps are parked in LDS until the end of the kernel: a (conditional) global store
@@ -78,10 +78,22 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
     const int t_row = tid >> 6, t_col = tid & 63;
     {
         // all of a thread's window loads are issued before any is stored: a load -> LDS-store loop with run-time bounds
-        // is not unrolled and pays one global round trip per iteration (stamped: 8.7 k of the tile's 39 k cycles)
-        constexpr int AMAX = 6;
+        // is not unrolled and pays one global round trip per iteration (stamped: 8.7 k of the tile's 39 k cycles).
+        // The upscaled_input window goes straight to its final place (sm; stage C adds the conv to it): every global
+        // read of the tile is in flight at once, here, and overlaps the other resident workgroup's arithmetic.
+        constexpr int AMAX = 6, UMAX = 14;
         const int total = 3 * p.LH * p.LW, plane = p.LH * p.LW;
-        float v[AMAX];
+        const int hw = eh * ew, utotal = 3 * hw, splane = p.EH * p.EW;
+        const float inv_hw = 1.0f / (float)hw, inv_ew = 1.0f / (float)ew;      // exact quotients for these small integers
+        const size_t cstride = (size_t)Hs * Ws;
+        const float* uib = p.ui + ((size_t)b * 3 * Hs + hy0) * Ws + hx0;
+        auto ui_pos = [&](int idx, int& c, int& sy, int& sx) {
+            c = (int)(((float)idx + 0.5f) * inv_hw);
+            const int rem = idx - c * hw;
+            sy = (int)(((float)rem + 0.5f) * inv_ew);
+            sx = rem - sy * ew;
+        };
+        float v[AMAX], uv[UMAX];
 #pragma unroll
         for (int k = 0; k < AMAX; ++k) {
             const int idx = tid + k * NT;
@@ -94,15 +106,39 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
             }
         }
 #pragma unroll
+        for (int k = 0; k < UMAX; ++k) {
+            const int idx = tid + k * NT;
+            uv[k] = 0.f;
+            if (idx < utotal) {
+                int c, sy, sx;
+                ui_pos(idx, c, sy, sx);
+                uv[k] = uib[c * cstride + (size_t)sy * Ws + sx];
+            }
+        }
+#pragma unroll
         for (int k = 0; k < AMAX; ++k) {
             const int idx = tid + k * NT;
             if (idx < total) lr[idx] = v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < UMAX; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < utotal) {
+                int c, sy, sx;
+                ui_pos(idx, c, sy, sx);
+                sm[c * splane + sy * p.EW + sx] = uv[k];
+            }
         }
         for (int idx = tid + AMAX * NT; idx < total; idx += NT) {      // larger windows (not reached for r <= 6 tiles)
             const int c = idx / plane, q = idx - c * plane;
             const int yy = q / p.LW, xx = q - yy * p.LW;
             const int iy = ly0 + yy, ix = lx0 + xx;
             lr[idx] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((size_t)b * 3 + c) * p.H + iy) * p.W + ix] : 0.f;
+        }
+        for (int idx = tid + UMAX * NT; idx < utotal; idx += NT) {     // larger windows (strong down-scaling ratios)
+            int c, sy, sx;
+            ui_pos(idx, c, sy, sx);
+            sm[c * splane + sy * p.EW + sx] = uib[c * cstride + (size_t)sy * Ws + sx];
         }
     }
     stamp();          // 1: stage A loads issued + written
@@ -126,7 +162,7 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
         // rr < 8 phases (r = 1, 2): NROW / rr waves share a phase and interleave its pixel pairs
         const int nparts = rr < NROW ? NROW / rr : 1;
         const int part = wv / rr;                       // 0 when rr >= NROW
-        for (int ph = wv % rr; ph < rr && part < nparts; ph += NROW) {
+        for (int ph = wv % rr; ph < rr && part < nparts && !(p.abl & 1); ph += NROW) {
             const int si = ph / r, sj = ph - si * r;
             // LR pixels whose phase-(si,sj) child lies in the t1 window [hy0-1, hy0+eh] x [hx0-1, hx0+ew] and the image
             const int ya = (Ya - si + r - 1) / r, yb = (Yb - si >= 0) ? (Yb - si) / r : -1;
@@ -184,17 +220,11 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
         // the 512 threads stay busy whatever the window shape (rows = q / npair through an exact float reciprocal)
         const int npair = (ew + 1) >> 1, nq = eh * npair;
         const float inv_np = 1.0f / (float)npair;
-        const size_t cstride = (size_t)Hs * Ws;
         const int tplane = TH1 * TW1, splane = p.EH * p.EW;
-        for (int q = tid; q < nq; q += NT) {
+        for (int q = tid; q < nq && !(p.abl & 2); q += NT) {
             const int sy = (int)(((float)q + 0.5f) * inv_np);
             const int sx = 2 * (q - sy * npair);
             const bool two = sx + 1 < ew;
-            const int Y = hy0 + sy, X = hx0 + sx;             // always inside the HR image
-            const size_t o = ((size_t)b * 3 * Hs + Y) * Ws + X;
-            float u[3][2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { u[c][0] = p.ui[o + c * cstride]; u[c][1] = two ? p.ui[o + c * cstride + 1] : 0.f; }
             f32x2 a0 = {b0, b0}, a1 = {b1, b1}, a2 = {b2, b2};
             const float* base = t1 + sy * TW1 + sx;           // t1 tile origin is (hy0-1, hx0-1)
 #pragma unroll
@@ -212,13 +242,15 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
                         a2 = __builtin_elementwise_fma(f32x2{wg2[k], wg2[k]}, pr[kx], a2);
                     }
                 }
-            float* sp = sm + sy * p.EW + sx;
+            float* sp = sm + sy * p.EW + sx;                  // holds upscaled_input since stage A
+            const f32x2 u0 = *reinterpret_cast<const f32x2*>(sp), u1 = *reinterpret_cast<const f32x2*>(sp + splane),
+                        u2 = *reinterpret_cast<const f32x2*>(sp + 2 * splane);
             if (two) {
-                *reinterpret_cast<f32x2*>(sp) = f32x2{a0[0] + u[0][0], a0[1] + u[0][1]};
-                *reinterpret_cast<f32x2*>(sp + splane) = f32x2{a1[0] + u[1][0], a1[1] + u[1][1]};
-                *reinterpret_cast<f32x2*>(sp + 2 * splane) = f32x2{a2[0] + u[2][0], a2[1] + u[2][1]};
+                *reinterpret_cast<f32x2*>(sp) = a0 + u0;
+                *reinterpret_cast<f32x2*>(sp + splane) = a1 + u1;
+                *reinterpret_cast<f32x2*>(sp + 2 * splane) = a2 + u2;
             } else {
-                sp[0] = a0[0] + u[0][0]; sp[splane] = a1[0] + u[1][0]; sp[2 * splane] = a2[0] + u[2][0];
+                sp[0] = a0[0] + u0[0]; sp[splane] = a1[0] + u1[0]; sp[2 * splane] = a2[0] + u2[0];
             }
         }
     }
@@ -228,7 +260,7 @@ __global__ __launch_bounds__(NT, OCC) void tail_fused_kernel(const TailParams p)
     // ---- stage D: antialiased resize taps + clamp: a thread owns one output column (its x taps are loaded once) ----
     {
         const int ox = ox0 + t_col;
-        if (ox < p.Wo) {
+        if (ox < p.Wo && !(p.abl & 4)) {
             const int x0 = p.xmin[ox] - hx0, nx = p.xsize[ox];
             float wx[8];
 #pragma unroll
@@ -285,9 +317,11 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     p.H = H; p.W = W; p.r = r; p.Ho = Ho; p.Wo = Wo; p.EH = EH; p.EW = EW; p.clamp01 = clamp01;
     static const int stamps_on = getenv("TUP_TAIL_STAMPS") ? 1 : 0;
     p.stamps = stamps_on;
+    static const int abl = getenv("TUP_TAIL_ABLATE") ? atoi(getenv("TUP_TAIL_ABLATE")) : 0;      // timing experiments only (results are wrong)
+    p.abl = abl;
     p.LH = (EH + 2) / r + 4; p.LW = ((EW + 2) / r + 4 + 1) & ~1;
     const int nfu = 3 * r * r;
-    const size_t lds = ((size_t)nfu * 28 + ((nfu + 1) & ~1) + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW) * sizeof(float);
+    const size_t lds = ((size_t)nfu * 28 + ((nfu + 1) & ~1) + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW + 2) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, two 512-thread workgroups per CU) or 2
     static const bool occ2 = getenv("TUP_TAIL_OCC2") != nullptr;

@@ -10,6 +10,7 @@
 // handful of fp32 planes.  conv1 still uses MFMA (im2col K = 27 padded to 32, one K-step) so
 // the VALU never limits the store stream.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -17,6 +18,25 @@ constexpr int TH = 8, TW = 32, HALO_W = TW + 2, HALO_H = TH + 2;
 constexpr int LW = 36;                                  // padded LDS row pitch (elements)
 constexpr int PLANE = HALO_H * LW;                      // 360
 constexpr int ZERO_BASE = 3 * PLANE;                    // a zero plane for the K padding (k >= 27)
+
+// Store one pixel group's packed outputs with full-line coalescing.  The MFMA layout leaves lane (g, p) with the 32 B
+// (chunks 2g, 2g+1) of pixel p, so "store chunk 2g, then chunk 2g+1" makes each store instruction write 16-B pieces at a
+// 32-B stride.  Lanes p and p^8 swap one chunk (DPP row_ror:8) so that the first instruction covers pixels 0-7 of the
+// group completely (8 x 128 B contiguous) and the second pixels 8-15.  row = out + first pixel of the group; npix =
+// pixels of the group inside the map.
+TUP_DEVICE void store_group_coalesced(bf16_t* row, int g, int p, const uint32_t (&pk)[8], int npix)
+{
+    const bool hi = p >= 8;
+    uint32_t keep[4], send[4], recv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { keep[q] = hi ? pk[4 + q] : pk[q]; send[q] = hi ? pk[q] : pk[4 + q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) recv[q] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send[q], 0x128, 0xf, 0xf, false);   // row_ror:8
+    const int px = p & 7, chunk = 2 * g + (hi ? 1 : 0);
+    bf16_t* o1 = row + px * 64 + chunk * 8;
+    if (px < npix) *reinterpret_cast<u32x4*>(o1) = hi ? u32x4{recv[0], recv[1], recv[2], recv[3]} : u32x4{keep[0], keep[1], keep[2], keep[3]};
+    if (px + 8 < npix) *reinterpret_cast<u32x4*>(o1 + 8 * 64) = hi ? u32x4{keep[0], keep[1], keep[2], keep[3]} : u32x4{recv[0], recv[1], recv[2], recv[3]};
+}
 
 __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
@@ -103,6 +123,137 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
         }
         *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
         *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    }
+}
+
+// Persistent form of the kernel above: a workgroup walks tiles blockIdx.x, + gridDim.x, ... .  conv1 is a 943 MB store
+// stream (128 B written per pixel against 12 B read) and the one-tile kernel pays a global round trip (halo loads ->
+// LDS) in front of every 32 KB of stores: 2.7 TB/s written.  Here the halo values are requested into registers TWO
+// tiles ahead (vA / vB alternate; LDS double-buffered, one barrier per tile), weights / bias / im2col offsets are set
+// up once per workgroup and the (element -> source offset) map of the staging once per thread: 3.2 TB/s (353 -> 295 us
+// at 8 x 720p).  What is left is the interaction of the scattered fp32 halo reads with the store stream: without the
+// reads the same kernel stores at 4.8 TB/s (timing ablation), and a dedicated loader wave did not beat this form.
+__global__ __launch_bounds__(256) void conv3x3_c3_persistent_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ in_mask, const bf16_t* __restrict__ out_mask,
+    bf16_t* __restrict__ out, int H, int W, int relu, int tilesX, int tilesY, int ntiles)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][4 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+
+    // staging map: element idx = tid + k*256 of the 3 haloed planes -> offset from the tile's origin pixel
+    constexpr int NST = (3 * PLANE + 255) / 256;         // 5
+    int goff[NST], dyx[NST];                               // dyx = (yy << 8) | xx, or -1 for elements never loaded
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int idx = tid + k * 256;
+        const int c = idx / PLANE, rem = idx - c * PLANE;
+        const int yy = rem / LW, xx = rem - yy * LW;
+        const bool used = idx < 3 * PLANE && xx < HALO_W;
+        goff[k] = (c * H + (yy - 1)) * W + (xx - 1);
+        dyx[k] = used ? ((yy << 8) | xx) : -1;
+    }
+    for (int i = tid; i < 2 * 4 * PLANE; i += 256) (&lds[0][0])[i] = f32_to_bf16(0.f);      // zero plane + row padding, once
+
+    bf16x8 wf[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) wf[ct] = *reinterpret_cast<const bf16x8*>(wp + (ct * 16 + p) * 32 + 8 * g);
+    f32x4 bv[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) bv[ct] = bias ? *reinterpret_cast<const f32x4*>(bias + g * 16 + ct * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        const int tap = k / 3, c = k - tap * 3;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        koff[j] = (k < 27) ? (c * PLANE + dy * LW + dx) : ZERO_BASE;
+    }
+
+    auto load_tile = [&](int t, float (&v)[NST]) {
+        const int tx = t % tilesX, r1 = t / tilesX;
+        const int ty = r1 % tilesY, b = r1 / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        const size_t origin = ((size_t)b * 3 * H + ty0) * W + tx0;
+        const bool interior = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + TW + 1 <= W;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            v[k] = 0.f;
+            bool ok = dyx[k] >= 0;
+            if (ok && !interior) {
+                const int iy = ty0 - 1 + (dyx[k] >> 8), ix = tx0 - 1 + (dyx[k] & 255);
+                ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            }
+            if (ok) {
+                const size_t gi = origin + goff[k];      // goff may be negative: size_t wrap-around is the subtraction
+                v[k] = x[gi];
+                if (in_mask && !(in_mask[gi] > 0.f)) v[k] = 0.f;      // ReLU backward fused into the load
+            }
+        }
+    };
+
+    float vA[NST], vB[NST];
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t < ntiles) load_tile(t, vA);
+    if (t + G < ntiles) load_tile(t + G, vB);
+    __syncthreads();                                        // zero fill done before the first staging stores
+    auto process = [&](int t, float (&v)[NST], int buf) {
+        bf16_t* L = lds[buf];
+#pragma unroll
+        for (int k = 0; k < NST; ++k)
+            if (dyx[k] >= 0) L[tid + k * 256] = f32_to_bf16(v[k]);
+        __syncthreads();
+        const int tx = t % tilesX, r1 = t / tilesX;
+        const int ty = r1 % tilesY, b = r1 / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * TW;
+        if (t + 2 * G < ntiles) load_tile(t + 2 * G, v);        // in flight under two tiles' MFMAs and stores
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) {
+            const int row = 2 * wave + (pg >> 1), x0 = (pg & 1) * 16;
+            const int pb = row * LW + x0 + p;
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = L[koff[j] + pb];
+            const int oy = ty0 + row, ox = tx0 + x0 + p;
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma16x16x32(wf[ct], pf, bv[ct]);
+            if (oy >= H) continue;                  // wave-uniform (a pixel group is one image row)
+            const bool ok = ox < W;
+            uint32_t pk[8], mw[8];
+            if (out_mask && ok) {
+                const bf16_t* mp = out_mask + (((size_t)b * H + oy) * W + ox) * 64 + g * 16;
+                const u32x4 m0 = *reinterpret_cast<const u32x4*>(mp), m1 = *reinterpret_cast<const u32x4*>(mp + 8);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { mw[q] = m0[q]; mw[4 + q] = m1[q]; }
+            }
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                float vv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vv[e] = acc[ct][e];                          // bias rode in the accumulator
+                    if (relu) vv[e] = fmaxf(vv[e], 0.f);
+                    if (out_mask && ok) {
+                        const int wi = (ct * 4 + e) >> 1;
+                        const float mv = __builtin_bit_cast(float, (e & 1) ? (mw[wi] & 0xffff0000u) : (mw[wi] << 16));
+                        if (!(mv > 0.f)) vv[e] = 0.f;
+                    }
+                }
+                pk[ct * 2 + 0] = pack_bf16x2(vv[0], vv[1]);
+                pk[ct * 2 + 1] = pack_bf16x2(vv[2], vv[3]);
+            }
+            store_group_coalesced(out + (((size_t)b * H + oy) * W + tx0 + x0) * 64, g, p, pk, W - (tx0 + x0));
+        }
+    };
+    while (t < ntiles) {
+        process(t, vA, 0);
+        t += G;
+        if (t >= ntiles) break;
+        process(t, vB, 1);
+        t += G;
     }
 }
 
@@ -202,6 +353,14 @@ extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* b
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nblk = (long long)tilesX * tilesY * B;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    static const bool one_tile = getenv("TUP_CONV1_ONE_TILE") != nullptr;      // A/B switch: the non-persistent kernel
+    if (!one_tile && (long long)B * 3 * H * W < (1LL << 31)) {
+        const unsigned grid = (unsigned)(nblk < 256 * 6 ? nblk : 256 * 6);
+        conv3x3_c3_persistent_kernel<<<dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+            x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY, (int)nblk);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     conv3x3_c3_kernel<<<dim3((unsigned)nblk), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY);
     TUP_CHECK_LAUNCH();

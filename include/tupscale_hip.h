@@ -318,6 +318,14 @@ int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const float* beta
 int tup_fused_attn_block_fwd(float* x, const float* gamma, const float* beta, const void* wh, const float* bh,
                              const float* bias_frag, const void* wproj, const float* bproj, int nwin, void* stream);
 
+/* One whole WindowTransformerBlock in place (model.py:153-172): x += proj(attention(qkv(norm1(x)))) followed by
+ * x += mlp.2(GELU(mlp.0(norm2(x)))) in ONE kernel: the residual stream of a 128-token tile stays in registers between
+ * the two halves.  Arguments: those of tup_fused_attn_block_fwd, then norm2 / mlp.0 / mlp.2 as in tup_fused_mlp_fwd. */
+int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const void* wh, const float* bh,
+                        const float* bias_frag, const void* wproj, const float* bproj,
+                        const float* gamma2, const float* beta2, const void* w1, const float* b1,
+                        const void* w2, const float* b2, int nwin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

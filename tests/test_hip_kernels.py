@@ -496,3 +496,32 @@ def test_fused_attention_block(dev, nwin):
                                packing.pack_proj_pairs(wp).to(dev), bp.to(dev)).cpu()
     err = (got - ref).abs().max().item()
     assert err <= 3e-2 + 2e-2 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("nwin", [1, 2, 5, 64])
+def test_fused_block_equals_two_halves(dev, nwin):
+    """tup_fused_block_fwd (whole WindowTransformerBlock, model.py:153-172, one kernel) against the attention-half kernel
+    followed by the MLP-half kernel: the same arithmetic on the same registers, so the results are identical; and both
+    against torch through the checks of the two halves above."""
+    from transformerupscaler_amd import ops, packing
+    g = torch.Generator().manual_seed(23)
+    M = nwin * 64
+    x = torch.randn((M, 192), generator=g).to(dev)
+    gm1 = (1 + 0.1 * torch.randn(192, generator=g)).to(dev); bt1 = (0.1 * torch.randn(192, generator=g)).to(dev)
+    gm2 = (1 + 0.1 * torch.randn(192, generator=g)).to(dev); bt2 = (0.1 * torch.randn(192, generator=g)).to(dev)
+    w = torch.randn((576, 192), generator=g) / 192 ** 0.5; b = 0.1 * torch.randn(576, generator=g)
+    wp = torch.randn((192, 192), generator=g) / 192 ** 0.5; bp = (0.1 * torch.randn(192, generator=g)).to(dev)
+    w1 = torch.randn((768, 192), generator=g) * 0.08; b1 = (0.2 * torch.randn(768, generator=g)).to(dev)
+    w2 = torch.randn((192, 768), generator=g) * 0.05; b2 = (0.2 * torch.randn(192, generator=g)).to(dev)
+    table = 0.5 * torch.randn((225, 12), generator=g)
+    wh, bh = packing.pack_qkv_heads(w, b)
+    wh, bh = wh.to(dev), bh.to(dev)
+    frag = ops.relpos_bias_expand(table.to(dev))
+    wpp = packing.pack_proj_pairs(wp).to(dev)
+    w1f, w2p = packing.pack_fc1_fused(w1).to(dev), packing.pack_linear(w2).to(dev)
+    two = ops.fused_attn_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp)
+    two = ops.fused_mlp(two, gm2, bt2, w1f, b1, w2p, b2)
+    one = ops.fused_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp, gm2, bt2, w1f, b1, w2p, b2)
+    assert torch.isfinite(one).all()
+    assert (one - two).abs().max().item() <= 1e-5, (one - two).abs().max().item()
+    assert (one - x).abs().max().item() > 0.1            # the block did something

@@ -44,12 +44,28 @@ __device__ __attribute__((aligned(16))) unsigned int tup_fa_sink[64 * 2];       
 // PROJ = true additionally runs attn.proj + the residual add (model.py:131,164) on the attention output while it is still
 // in registers: the 12 per-head O^T tiles ARE the token fragments of that GEMM (two heads = one K-step of 32, weight
 // columns pre-permuted to match), W_proj streams through the two weight slots in 3 chunks, and x is updated in place.
-template <bool PROJ>
+//
+// MLP = true (with PROJ) appends the second half of the block, x += mlp.2(GELU(mlp.0(LayerNorm2(x)))) (model.py:165-171): the
+// proj accumulators + bias + residual ARE the new residual stream of this wave's 32 tokens, in the layout of the fused
+// MLP's FC2 accumulators (fused_blocks.hip), so LayerNorm2 and its MFMA fragments are computed from registers, the chunk
+// loop of that kernel follows, and x is written once per block -- one fp32 write + one read of x (94 MB each at B = 8)
+// and the load / store phases of a second kernel disappear.  LDS: W1 double buffer = the two weight slots, W2 chunk over
+// the (by then dead) K/V tiles and qkv bias, b1 behind it; 75 KB, two workgroups per CU as before.
+struct MlpArgs {
+    const float* gamma2; const float* beta2;
+    const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2;
+};
+constexpr int HID = 768;
+constexpr int M_W2_OFF = 2 * FW_BYTES, M_B1_OFF = 3 * FW_BYTES, FB_LDS = M_B1_OFF + HID * 4;       // 76,800 B
+
+template <bool PROJ, bool MLP = false>
 __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const bf16_t* __restrict__ wh, const float* __restrict__ bh, const float* __restrict__ bias_frag,
-    bf16_t* __restrict__ out, int nwin, const bf16_t* __restrict__ wproj, const float* __restrict__ bproj, float* __restrict__ xio)
+    bf16_t* __restrict__ out, int nwin, const bf16_t* __restrict__ wproj, const float* __restrict__ bproj, float* __restrict__ xio,
+    const MlpArgs ma)
 {
+    static_assert(!MLP || PROJ, "the MLP half follows the proj");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, pl = lane & 15;
@@ -60,6 +76,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 
     float* qb = reinterpret_cast<float*>(smem + QB_OFF);
     for (int i = tid; i < HEADS * 48; i += 256) qb[i] = bh[i];
+    if constexpr (MLP) {           // mlp.0's bias: behind everything the attention half uses, staged before any DMA is in flight
+        float* b1s = reinterpret_cast<float*>(smem + M_B1_OFF);
+        for (int i = tid; i < HID / 4; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(ma.b1)[i];
+    }
 
     // head h's weight slot by DMA: slot s = u*256 + tid -> k-tile u >> 1, row (u & 1)*32 + (tid >> 3), logical chunk
     // (tid & 7) ^ ((tid >> 4) & 7) (swizzle on the source side)
@@ -139,6 +159,24 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
         for (int u = 0; u < 6; ++u)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+    };
+
+    // MLP weight stream (same slot geometry and thread map as the qkv / proj slots)
+    const bf16_t* w1_thr = MLP ? ma.w1 + (size_t)(tid >> 3) * DIM + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 : nullptr;
+    const bf16_t* w2_thr = MLP ? ma.w2 + (size_t)(tid >> 3) * HID + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 : nullptr;
+    auto dma_w1_piece = [&](int j, int buf, int u) {
+        char* dst = smem + buf * FW_BYTES + wave * 1024;
+        const bf16_t* src = w1_thr + (size_t)j * 64 * DIM;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
+                                         (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+    };
+    auto dma_w2 = [&](int j) {
+        char* dst = smem + M_W2_OFF + wave * 1024;
+        const bf16_t* src = w2_thr + j * 64;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)((u >> 1) * 64 + (u & 1) * 32) * HID),
                                              (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
     };
 
@@ -284,6 +322,12 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // everyone's pieces; everyone finished chunk c-1
             if (c == 1) dma_wp(2, 0);
+            if constexpr (MLP) {
+                if (c == 2) {          // slot 1 (proj chunk 1) is free: mlp.0's first chunk lands under the last proj chunk
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) dma_w1_piece(0, 1, u);
+                }
+            }
             const uint32_t wb = sbase + (uint32_t)((c & 1) * FW_BYTES) + w_off;
             bf16x8 wf[3][4];
             auto ld = [&](int step, int slot) {
@@ -311,19 +355,183 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (!active) return;
+        if constexpr (!MLP) {
+            if (!active) return;
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+            for (int tg = 0; tg < 2; ++tg) {
+                float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
-            for (int n = 0; n < 12; ++n) {
-                const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;       // weight rows are permuted per 64-group
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + col);
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bproj + col);
-                f32x4 ov;
+                for (int n = 0; n < 12; ++n) {
+                    const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;       // weight rows are permuted per 64-group
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + col);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bproj + col);
+                    f32x4 ov;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = acc2[tg][n][e] + bv[e] + rv[e];
-                *reinterpret_cast<f32x4*>(xr + col) = ov;
+                    for (int e = 0; e < 4; ++e) ov[e] = acc2[tg][n][e] + bv[e] + rv[e];
+                    *reinterpret_cast<f32x4*>(xr + col) = ov;
+                }
+            }
+        } else {
+            // ---- second half of the block.  acc2 <- the new residual stream x + proj + b_proj (inactive waves carry a
+            // copy of the last window and take part in every barrier; only their final store is skipped) ----
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+#pragma unroll
+                for (int n = 0; n < 12; ++n) {
+                    const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + col);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bproj + col);
+                    acc2[tg][n] = (acc2[tg][n] + bv) + rv;
+                }
+            }
+            // LayerNorm2 from the accumulators: this lane holds 48 of its token's 192 channels, the other three lane
+            // groups the rest.  K-step st of FC1 contracts over channels 64*(st>>1) + 16g + 8*(st&1) .. +8 = accumulators
+            // n = 2st, 2st+1 (packing.pack_fc1_fused), so the B fragments are packed straight from them.
+            bf16x8 tf2[2][6];
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                float sum = 0.f;
+#pragma unroll
+                for (int n = 0; n < 12; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sum += acc2[tg][n][e];
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float mean = sum * (1.0f / DIM);
+                float ss = 0.f;
+#pragma unroll
+                for (int n = 0; n < 12; ++n)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = acc2[tg][n][e] - mean; ss += d * d; }
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float rstd = rsqrtf(ss * (1.0f / DIM) + 1e-5f);
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int c = 64 * (st >> 1) + 16 * g + 8 * (st & 1) + 4 * hh;
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(ma.gamma2 + c);
+                        const f32x4 bt = *reinterpret_cast<const f32x4*>(ma.beta2 + c);
+                        const f32x4 b2v = *reinterpret_cast<const f32x4*>(ma.b2 + c);
+                        const f32x4 v = acc2[tg][2 * st + hh];
+                        float o4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
+                        pk[2 * hh] = pack_bf16x2(o4[0], o4[1]);
+                        pk[2 * hh + 1] = pack_bf16x2(o4[2], o4[3]);
+                        acc2[tg][2 * st + hh] = v + b2v;               // FC2 accumulates onto x + b2
+                    }
+                    tf2[tg][st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+                }
+            }
+
+            // ---- the chunk loop of fused_mlp_v2_kernel (fused_blocks.hip); W1 chunk j lives in slot (j + 1) & 1 ----
+            const uint32_t w2_off0 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g)), w2_off1 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g + 1));
+            const uint32_t b1_base = sbase + M_B1_OFF + (uint32_t)(g * 64);
+            for (int j = 0; j < HID / 64; ++j) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of W1 chunk j have landed
+                __syncthreads();                                       // everyone's have; everyone is done with chunk j-1 / the proj
+                dma_w2(j);
+                const bool more = j + 1 < HID / 64;
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t wb1 = sbase + (uint32_t)(((j + 1) & 1) * FW_BYTES);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    f32x4 acc1[2][2];
+#pragma unroll
+                    for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) acc1[tg][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    f32x4 bb[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+                        bb[hh] = __builtin_bit_cast(f32x4, lds_read_b128_asm(b1_base + (uint32_t)((j * 64 + (2 * s + hh) * 4) * 4)));
+                    bf16x8 wf[3][2];
+                    auto ld1 = [&](int step, int slot) {
+                        const uint32_t a = wb1 + ((w_off ^ ((uint32_t)(step & 1) << 6)) + (uint32_t)((step >> 1) * (64 * 128) + 2 * s * 2048));
+                        wf[slot][0] = lds_read_b128_asm(a);
+                        wf[slot][1] = lds_read_b128_asm(a + 2048);
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    ld1(0, 0);
+                    ld1(1, 1);
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const int cur = step % 3;
+                        if (step + 2 < 6) { ld1(step + 2, (step + 2) % 3); lds_wait<4>(); }
+                        else if (step + 1 < 6) lds_wait<2>();
+                        else lds_wait<0>();
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) acc1[tg][hh] = mfma16x16x32(wf[cur][hh], tf2[tg][step], acc1[tg][hh]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s == 0 && more) { dma_w1_piece(j + 1, j & 1, step); __builtin_amdgcn_sched_barrier(0); }
+                    }
+                    if (s == 0) {
+                        if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W2 chunk j landed (younger: the W1 prefetch)
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    bf16x8 w2f[8];
+                    const uint32_t w2a = sbase + (s ? w2_off1 : w2_off0);
+                    auto w2addr = [&](int n) { return w2a + (uint32_t)((n >> 2) * (64 * 128) + (n & 3) * 2048); };
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) w2f[n] = lds_read_b128_asm(w2addr(n));
+                    __builtin_amdgcn_sched_barrier(0);
+                    bf16x8 hfr[2];
+#pragma unroll
+                    for (int tg = 0; tg < 2; ++tg) {
+                        f32x2 gv[4];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            gv[hh * 2 + 0] = f32x2{acc1[tg][hh][0] + bb[hh][0], acc1[tg][hh][1] + bb[hh][1]};
+                            gv[hh * 2 + 1] = f32x2{acc1[tg][hh][2] + bb[hh][2], acc1[tg][hh][3] + bb[hh][3]};
+                        }
+                        gelu_erf2_batch<4>(gv);
+                        u32x4 pk;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pk[q] = pack_bf16x2(gv[q][0], gv[q][1]);
+                        hfr[tg] = __builtin_bit_cast(bf16x8, pk);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds_wait<4>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) w2f[n] = lds_read_b128_asm(w2addr(8 + n));
+                    lds_wait<4>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 4; n < 8; ++n)
+#pragma unroll
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    lds_wait<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+#pragma unroll
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][8 + n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][8 + n]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!active) return;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+#pragma unroll
+                for (int n = 0; n < 12; ++n)
+                    *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
             }
         }
     }
@@ -345,7 +553,7 @@ extern "C" int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const 
         attr_set = true;
     }
     fused_qkv_attn_kernel<false><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, (bf16_t*)out, nwin, nullptr, nullptr, nullptr);
+        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, (bf16_t*)out, nwin, nullptr, nullptr, nullptr, MlpArgs{});
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -363,7 +571,28 @@ extern "C" int tup_fused_attn_block_fwd(float* x, const float* gamma, const floa
         attr_set = true;
     }
     fused_qkv_attn_kernel<true><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x);
+        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, MlpArgs{});
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// One whole WindowTransformerBlock, in place (model.py:153-172): x += proj(attention(qkv(norm1(x)))); x += mlp(norm2(x)).
+// Arguments as tup_fused_attn_block_fwd followed by those of tup_fused_mlp_fwd (w1 packed by packing.pack_fc1_fused).
+extern "C" int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const void* wh, const float* bh,
+                                   const float* bias_frag, const void* wproj, const float* bproj,
+                                   const float* gamma2, const float* beta2, const void* w1, const float* b1,
+                                   const void* w2, const float* b2, int nwin, void* stream)
+{
+    if (nwin <= 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const MlpArgs ma{gamma2, beta2, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
+    fused_qkv_attn_kernel<true, true><<<dim3((nwin + 1) / 2), dim3(256), FB_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
+        x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, ma);
     TUP_CHECK_LAUNCH();
     return 0;
 }

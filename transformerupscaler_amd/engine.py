@@ -21,7 +21,7 @@ from .weights import BLOCKS, VALID_SCALES, upsampler_layout
 stage_timer = None
 # inference fusion level of the attention half: 2 = norm1 + qkv + attention + proj + residual in one kernel,
 # 1 = norm1 + qkv + attention (proj separate), 0 = separate kernels
-fuse_attention = 0 if os.environ.get("TUP_NO_FUSED_ATTN") else int(os.environ.get("TUP_FUSED_ATTN_LEVEL", "2"))
+fuse_attention = 0 if os.environ.get("TUP_NO_FUSED_ATTN") else int(os.environ.get("TUP_FUSED_ATTN_LEVEL", "3"))
 
 
 class _NullCtx:
@@ -55,6 +55,12 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     for i in range(BLOCKS):
         qkv = None
+        if fuse_blocks and fuse_attention >= 3 and capture is None and f"b{i}.proj.wpp" in pk:
+            # the whole block in one kernel: the residual stream of a token tile stays in registers between the halves
+            ops.fused_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
+                            pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
+                            pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
+            continue
         if fuse_blocks and fuse_attention == 2 and capture is None and f"b{i}.proj.wpp" in pk:
             # the whole attention half in one kernel, in place: neither the qkv nor the attention-output tensor exists
             ops.fused_attn_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],

@@ -230,6 +230,19 @@ def fused_attn_block(x, gamma, beta, wh, bh, bias_frag, wproj, bproj):
     return x
 
 
+def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2):
+    """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion)."""
+    M = x.shape[0]
+    assert M % 64 == 0
+    _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
+              _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
+              _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"),
+              _chk(gamma2, F32, (192,), "gamma2"), _chk(beta2, F32, (192,), "beta2"),
+              _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, BF16, (192, 768), "w2"), _chk(b2, F32, (192,), "b2"),
+              M // 64, _stream())
+    return x
+
+
 def fused_mlp(x, gamma, beta, w1, b1, w2, b2):
     """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip)."""
     M = x.shape[0]

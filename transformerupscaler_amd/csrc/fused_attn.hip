@@ -391,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             bf16x8 tf2[2][6];
 #pragma unroll
             for (int tg = 0; tg < 2; ++tg) {
-                float sum = 0.f;
+                float sum = 0.f;             // same summation order as fused_mlp_v2_kernel: the two kernels agree bit for bit
 #pragma unroll
-                for (int n = 0; n < 12; ++n)
+                for (int st = 0; st < 6; ++st)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) sum += acc2[tg][n][e];
+                    for (int e = 0; e < 4; ++e) sum += acc2[tg][2 * st][e] + acc2[tg][2 * st + 1][e];
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
                 const float mean = sum * (1.0f / DIM);

@@ -577,14 +577,29 @@ __global__ __launch_bounds__(256) void conv5x5_border_fix_kernel(
     const int y = Y / r, si = Y - y * r, xx0 = X / r, sj = X - xx0 * r;
     const int sp = si * r + sj;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int tap = 0; tap < 25; ++tap) {
-        const int iy = y + tap / 5 - 2, ix = xx0 + tap % 5 - 2;
-        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-        const float f = bf16_to_f32(x[(((size_t)b * H + iy) * W + ix) * 64 + lane]);
-        const bf16_t* wb = wv + (((size_t)v * nout) * 25 + tap) * 64 + lane;      // [v][n][tap][ci]
-        a0 = fmaf(f, bf16_to_f32(wb[(size_t)(0 * rr + sp) * 25 * 64]), a0);
-        a1 = fmaf(f, bf16_to_f32(wb[(size_t)(1 * rr + sp) * 25 * 64]), a1);
-        a2 = fmaf(f, bf16_to_f32(wb[(size_t)(2 * rr + sp) * 25 * 64]), a2);
+    // one tap ROW (5 taps, 20 loads) in flight at a time: the fully rolled loop paid a global round trip per tap, the fully
+    // unrolled one cost occupancy (measured slower)
+#pragma unroll 1
+    for (int ty = 0; ty < 5; ++ty) {
+        const int iy = y + ty - 2;
+        if (iy < 0 || iy >= H) continue;                       // wave-uniform
+        float fv[5], w0[5], w1[5], w2[5];
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+            const int ix = xx0 + tx - 2, tap = ty * 5 + tx;
+            const bool in = ix >= 0 && ix < W;
+            const bf16_t* wb = wv + (((size_t)v * nout) * 25 + tap) * 64 + lane;      // [v][n][tap][ci]
+            fv[tx] = in ? bf16_to_f32(x[(((size_t)b * H + iy) * W + ix) * 64 + lane]) : 0.f;
+            w0[tx] = bf16_to_f32(wb[(size_t)(0 * rr + sp) * 25 * 64]);
+            w1[tx] = bf16_to_f32(wb[(size_t)(1 * rr + sp) * 25 * 64]);
+            w2[tx] = bf16_to_f32(wb[(size_t)(2 * rr + sp) * 25 * 64]);
+        }
+#pragma unroll
+        for (int tx = 0; tx < 5; ++tx) {
+            a0 = fmaf(fv[tx], w0[tx], a0);
+            a1 = fmaf(fv[tx], w1[tx], a1);
+            a2 = fmaf(fv[tx], w2[tx], a2);
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }

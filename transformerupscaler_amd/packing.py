@@ -16,10 +16,27 @@ from .weights import BLOCKS, upsampler_layout
 _PERM64 = torch.tensor([((n >> 2) & 3) * 16 + (n >> 4) * 4 + (n & 3) for n in range(64)], dtype=torch.long)
 
 
+_IDX_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _dev_index(key, build, device) -> torch.Tensor:
+    """Index tensors are built once per device: the training loop repacks every weight after every optimizer step, and
+    a host-built index means one host-to-device copy per packing call."""
+    k = (key, str(device))
+    t = _IDX_CACHE.get(k)
+    if t is None:
+        t = _IDX_CACHE[k] = build().to(device)
+    return t
+
+
+def _perm64(device) -> torch.Tensor:
+    return _dev_index("perm64", lambda: _PERM64, device)
+
+
 def perm_rows64(w: torch.Tensor) -> torch.Tensor:
     n = w.shape[0]
     assert n % 64 == 0
-    idx = (torch.arange(n // 64).view(-1, 1) * 64 + _PERM64.view(1, -1)).reshape(-1).to(w.device)
+    idx = _dev_index(("rows64", n), lambda: (torch.arange(n // 64).view(-1, 1) * 64 + _PERM64.view(1, -1)).reshape(-1), w.device)
     return w.index_select(0, idx)
 
 
@@ -29,7 +46,7 @@ def pack_conv_c64(weight: torch.Tensor, bias, r: int):
     assert cin == 64 and cout == 64 * r * r and weight.shape[2:] == (3, 3)
     w = weight.reshape(64, r * r, 64, 9)                 # [c][sp][cin][tap]  (cout = c*r*r + sp)
     w = w.permute(1, 3, 0, 2)                            # [sp][tap][c][cin]
-    w = w.index_select(2, _PERM64.to(w.device))          # row n_local <- channel perm[n_local]
+    w = w.index_select(2, _perm64(w.device))          # row n_local <- channel perm[n_local]
     b = None if bias is None else bias.reshape(64, r * r).t().contiguous().float()
     return w.unsqueeze(1).contiguous().to(torch.bfloat16), b       # [ntile][in-chunk = 1][9][64][64]
 
@@ -69,10 +86,11 @@ def pack_fc1_fused(weight: torch.Tensor):
     """mlp.0 weight for tup_fused_mlp_fwd: pack_linear plus a column permutation.  K-step st of the kernel's FC1, lane
     group g, element j contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j -- the channels whose residual the same
     lane carries in its FC2 accumulators -- so packed column 32st + 8g + j holds that channel."""
-    k = torch.arange(192)
-    st, g, j = k // 32, (k % 32) // 8, k % 8
-    src = 64 * (st // 2) + 16 * g + 8 * (st % 2) + j
-    return pack_linear(weight)[:, src.to(weight.device)].contiguous()
+    def build():
+        k = torch.arange(192)
+        st, g, j = k // 32, (k % 32) // 8, k % 8
+        return 64 * (st // 2) + 16 * g + 8 * (st % 2) + j
+    return pack_linear(weight).index_select(1, _dev_index("fc1_fused", build, weight.device)).contiguous()
 
 
 def pack_qkv_heads(weight: torch.Tensor, bias: torch.Tensor, heads: int = 12):
@@ -164,7 +182,7 @@ def pack_conv_c64_dgrad(weight: torch.Tensor, r: int):
     PixelShuffle^-1): bf16 [1][r*r][9][64 rows = cin][64 = c]."""
     w = weight.reshape(64, r * r, 64, 3, 3).flip(3, 4).reshape(64, r * r, 64, 9)    # [c][sp][cin][tap']
     w = w.permute(1, 3, 2, 0)                                                       # [sp][tap'][cin][c]
-    w = w.index_select(2, _PERM64.to(w.device))
+    w = w.index_select(2, _perm64(w.device))
     return w.unsqueeze(0).contiguous().to(torch.bfloat16)
 
 
@@ -256,7 +274,7 @@ def pack_conv_c64_stride2(weight: torch.Tensor, bias):
                     ky, kx = 2 * (dy - 1) + si + 1, 2 * (dx - 1) + sj + 1
                     if 0 <= ky <= 2 and 0 <= kx <= 2:
                         w[si * 2 + sj, dy * 3 + dx] = weight[:, :, ky, kx]
-    w = w.index_select(2, _PERM64.to(w.device))
+    w = w.index_select(2, _perm64(w.device))
     b = None if bias is None else bias.reshape(1, 64).contiguous().float()
     return w.unsqueeze(0).contiguous().to(torch.bfloat16), b
 
@@ -274,7 +292,7 @@ def pack_conv_c64_stride2_dgrad(weight: torch.Tensor):
                     ky, kx = si + 1 - 2 * (dy - 1), sj + 1 - 2 * (dx - 1)
                     if 0 <= ky <= 2 and 0 <= kx <= 2:
                         w[si * 2 + sj, dy * 3 + dx] = weight[:, :, ky, kx].t()
-    w = w.index_select(2, _PERM64.to(w.device))
+    w = w.index_select(2, _perm64(w.device))
     return w.unsqueeze(1).contiguous().to(torch.bfloat16)
 
 

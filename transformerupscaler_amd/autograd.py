@@ -215,7 +215,11 @@ class _FastTransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         reducer = getattr(ctx.module, "_grad_reducer", None)
-        grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout, reducer)
+        ops.zero_pool_begin(gout.device)
+        try:
+            grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout, reducer)
+        finally:
+            ops.zero_pool_end()
         if reducer is not None:
             grads = reducer.finish()          # averaged over ranks (views of the flat bucket buffer)
         ctx.sv = None

@@ -137,7 +137,11 @@ class _ResidualTransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         reducer = getattr(ctx.module, "_grad_reducer", None)
-        grads = backward_train(ctx.pk, ctx.sv, gout, reducer)
+        ops.zero_pool_begin(gout.device)
+        try:
+            grads = backward_train(ctx.pk, ctx.sv, gout, reducer)
+        finally:
+            ops.zero_pool_end()
         if reducer is not None:
             grads = reducer.finish()
         ctx.sv = None

@@ -6,6 +6,8 @@ on the caller's current HIP stream.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -33,6 +35,36 @@ def _chk(t: torch.Tensor, dtype, shape=None, name="tensor"):
 
 def _opt(t, dtype, shape, name):
     return None if t is None else _chk(t, dtype, shape, name)
+
+
+# ---- zero pool: the backward pass needs ~130 small zero-initialised fp32 buffers per step (atomically accumulated weight /
+# bias gradients).  One torch.zeros of the whole lot + views replaces 130 fill launches.  The pool is a fresh allocation per
+# backward pass and stays alive as long as any gradient view does, so there is no reuse hazard. ----
+_zero_pool = None          # [tensor, next free offset (floats)]
+_ZERO_POOL_FLOATS = int(os.environ.get("TUP_ZERO_POOL_FLOATS", str(6 * 1024 * 1024)))
+
+
+def zero_pool_begin(device):
+    global _zero_pool
+    if _ZERO_POOL_FLOATS > 0:
+        _zero_pool = [torch.zeros((_ZERO_POOL_FLOATS,), dtype=F32, device=device), 0]
+
+
+def zero_pool_end():
+    global _zero_pool
+    _zero_pool = None
+
+
+def _zeros(shape, device):
+    n = 1
+    for d in shape:
+        n *= int(d)
+    zp = _zero_pool
+    if zp is not None and zp[0].device == torch.device(device) and zp[1] + n <= zp[0].numel():
+        off = zp[1]
+        zp[1] = off + ((n + 63) // 64) * 64          # 256-byte aligned slices
+        return zp[0][off:off + n].view(shape)
+    return torch.zeros(shape, dtype=F32, device=device)
 
 
 def conv1(x, wp, bias, relu=True, in_mask=None, out_mask=None):
@@ -288,7 +320,7 @@ def gemm_wgrad(p, q, out=None):
     NJ = q.shape[1]
     assert q.shape[0] == M and NI % 64 == 0 and NJ % 64 == 0
     if out is None:
-        out = torch.zeros((NI, NJ), dtype=F32, device=p.device)
+        out = _zeros((NI, NJ), p.device)
     _lib.call("tup_gemm_wgrad", _chk(p, p.dtype, None, "p"), {BF16: 0, F32: 1}[p.dtype], NI,
               _chk(q, q.dtype, None, "q"), {BF16: 0, F32: 1}[q.dtype], NJ, _chk(out, F32, (NI, NJ), "out"), NJ,
               M, NI, NJ, _stream())
@@ -298,7 +330,7 @@ def gemm_wgrad(p, q, out=None):
 def patch_wgrad(p, fmap, reflect):
     B, H, W, C = fmap.shape
     _, _, nwy, nwx = window_geometry(H, W)
-    out = torch.zeros((192, 4096), dtype=F32, device=p.device)
+    out = _zeros((192, 4096), p.device)
     _lib.call("tup_patch_wgrad", _chk(p, F32, (B * nwy * nwx * 64, 192), "p"), _chk(fmap, BF16, None, "map"),
               out.data_ptr(), B, H, W, int(reflect), _stream())
     return out
@@ -307,7 +339,7 @@ def patch_wgrad(p, fmap, reflect):
 def colsum(g, out=None, rowmask=None):
     M, N = g.shape
     if out is None:
-        out = torch.zeros((N,), dtype=F32, device=g.device)
+        out = _zeros((N,), g.device)
     _lib.call("tup_colsum", _chk(g, g.dtype, None, "g"), {BF16: 0, F32: 1}[g.dtype], N, _chk(out, F32, (N,), "out"),
               M, N, _opt(rowmask, torch.uint8, (M,), "rowmask"), _stream())
     return out
@@ -316,8 +348,8 @@ def colsum(g, out=None, rowmask=None):
 def layernorm_bwd(gy, x, mean, rstd, gamma, gres=None):
     M = x.shape[0]
     dx = torch.empty((M, 192), dtype=F32, device=x.device)
-    dg = torch.zeros((192,), dtype=F32, device=x.device)
-    db = torch.zeros((192,), dtype=F32, device=x.device)
+    dg = _zeros((192,), x.device)
+    db = _zeros((192,), x.device)
     _lib.call("tup_layernorm_bwd", _chk(gy, BF16, (M, 192), "gy"), _chk(x, F32, (M, 192), "x"), _chk(mean, F32, (M,), "mean"),
               _chk(rstd, F32, (M,), "rstd"), _chk(gamma, F32, (192,), "gamma"), _opt(gres, F32, (M, 192), "gres"),
               dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, _stream())
@@ -342,7 +374,7 @@ def window_attn_bwd(qkv, gout, bias_t, bias_n, drop_p=0.0, drop_seed=0):
     M = qkv.shape[0]
     assert M % 64 == 0
     gqkv = torch.empty((M, 576), dtype=BF16, device=qkv.device)
-    dbias = torch.zeros((12, 4, 4, 64, 4), dtype=F32, device=qkv.device)
+    dbias = _zeros((12, 4, 4, 64, 4), qkv.device)
     _lib.call("tup_window_attn_bwd", _chk(qkv, BF16, (M, 576), "qkv"), _chk(gout, BF16, (M, 192), "gout"),
               _chk(bias_t, F32, (12, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (12, 4, 4, 64, 4), "bias_n"),
               gqkv.data_ptr(), dbias.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
@@ -372,8 +404,8 @@ def conv_c64_wgrad(x, gmap, gr=1):
     """-> (dwp fp32 [gr*gr][64][9][64] (sp, co, tap, ci), dbias fp32 [gr*gr][64])."""
     B, H, W, C = x.shape
     assert C == 64 and tuple(gmap.shape) == (B, H * gr, W * gr, 64)
-    dwp = torch.zeros((gr * gr, 64, 9, 64), dtype=F32, device=x.device)
-    db = torch.zeros((gr * gr, 64), dtype=F32, device=x.device)
+    dwp = _zeros((gr * gr, 64, 9, 64), x.device)
+    db = _zeros((gr * gr, 64), x.device)
     for sp in range(gr * gr):
         _lib.call("tup_conv3x3_c64_wgrad", _chk(x, BF16, None, "x"), _chk(gmap, BF16, None, "gmap"), dwp[sp].data_ptr(),
                   db[sp].data_ptr(), B, H, W, gr, sp, _stream())
@@ -383,8 +415,8 @@ def conv_c64_wgrad(x, gmap, gr=1):
 def conv_thin_wgrad(x, gpl, want_bias):
     B, H, W, C = x.shape
     assert C == 64
-    dwp = torch.zeros((3, 9, 64), dtype=F32, device=x.device)
-    db = torch.zeros((3,), dtype=F32, device=x.device) if want_bias else None
+    dwp = _zeros((3, 9, 64), x.device)
+    db = _zeros((3,), x.device) if want_bias else None
     _lib.call("tup_conv3x3_thin_wgrad", _chk(x, BF16, None, "x"), _chk(gpl, F32, (B, 3, H, W), "gpl"), dwp.data_ptr(),
               None if db is None else db.data_ptr(), B, H, W, _stream())
     return dwp, db
@@ -406,8 +438,8 @@ def conv1_wgrad_direct(x, gmap):
     """The original VALU kernel (tup_conv3x3_c3_wgrad), kept for the kernel-level test."""
     B, C, H, W = x.shape
     assert C == 3
-    dw = torch.zeros((64, 3, 3, 3), dtype=F32, device=x.device)
-    db = torch.zeros((64,), dtype=F32, device=x.device)
+    dw = _zeros((64, 3, 3, 3), x.device)
+    db = _zeros((64,), x.device)
     _lib.call("tup_conv3x3_c3_wgrad", _chk(x, F32, None, "x"), _chk(gmap, BF16, (B, H, W, 64), "gmap"), dw.data_ptr(),
               db.data_ptr(), B, H, W, _stream())
     return dw, db
@@ -416,8 +448,8 @@ def conv1_wgrad_direct(x, gmap):
 def conv_planar_wgrad(x, gpl, r):
     B, C, H, W = x.shape
     cout = 3 * r * r
-    dw = torch.zeros((cout, 3, 3, 3), dtype=F32, device=x.device)
-    db = torch.zeros((cout,), dtype=F32, device=x.device)
+    dw = _zeros((cout, 3, 3, 3), x.device)
+    db = _zeros((cout,), x.device)
     _lib.call("tup_conv3x3_planar_wgrad", _chk(x, F32, None, "x"), _chk(gpl, F32, (B, 3, H * r, W * r), "gpl"),
               dw.data_ptr(), db.data_ptr(), B, H, W, r, _stream())
     return dw, db
@@ -527,8 +559,8 @@ def layernorm128(x, gamma, beta, save_stats=False):
 def layernorm128_bwd(gy, x, mean, rstd, gamma, gres=None):
     M = x.shape[0]
     dx = torch.empty((M, 128), dtype=F32, device=x.device)
-    dg = torch.zeros((128,), dtype=F32, device=x.device)
-    db = torch.zeros((128,), dtype=F32, device=x.device)
+    dg = _zeros((128,), x.device)
+    db = _zeros((128,), x.device)
     _lib.call("tup_layernorm128_bwd", _chk(gy, BF16, (M, 128), "gy"), _chk(x, F32, (M, 128), "x"), _chk(mean, F32, (M,), "mean"),
               _chk(rstd, F32, (M,), "rstd"), _chk(gamma, F32, (128,), "gamma"), _opt(gres, F32, (M, 128), "gres"),
               dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, _stream())
@@ -538,7 +570,7 @@ def layernorm128_bwd(gy, x, mean, rstd, gamma, gres=None):
 def rt_patch_wgrad(p, fmap):
     """fp32 [128][4096] = p^T patches(fmap); p fp32 [B*T][128] (plain token grid), fmap NHWC bf16."""
     B, H, W, C = fmap.shape
-    out = torch.zeros((128, 4096), dtype=F32, device=p.device)
+    out = _zeros((128, 4096), p.device)
     _lib.call("tup_rt_patch_wgrad", _chk(p, F32, (B * (H // 8) * (W // 8), 128), "p"), _chk(fmap, BF16, None, "map"),
               out.data_ptr(), B, H, W, _stream())
     return out
@@ -567,8 +599,8 @@ def conv_c64_wgrad_s2d(x, gmap, xr):
     """Stride-xr conv weight gradient: fp32 [xr*xr][64 co][9][64 ci] block-tap gradients + bias gradient [64]."""
     B, H, W, C = gmap.shape
     assert tuple(x.shape) == (B, H * xr, W * xr, 64)
-    dwp = torch.zeros((xr * xr, 64, 9, 64), dtype=F32, device=x.device)
-    db = torch.zeros((64,), dtype=F32, device=x.device)
+    dwp = _zeros((xr * xr, 64, 9, 64), x.device)
+    db = _zeros((64,), x.device)
     for sp in range(xr * xr):
         _lib.call("tup_conv3x3_c64_wgrad_s2d", _chk(x, BF16, None, "x"), _chk(gmap, BF16, None, "gmap"), dwp[sp].data_ptr(),
                   db.data_ptr() if sp == 0 else None, B, H, W, xr, sp, _stream())
@@ -712,7 +744,7 @@ def window_attn_bwd_h(qkv, gout, bias_t, bias_n, heads, drop_p=0.0, drop_seed=0)
     M = qkv.shape[0]
     assert M % 64 == 0
     gqkv = torch.empty((M, 48 * heads), dtype=BF16, device=qkv.device)
-    dbias = torch.zeros((heads, 4, 4, 64, 4), dtype=F32, device=qkv.device)
+    dbias = _zeros((heads, 4, 4, 64, 4), qkv.device)
     _lib.call("tup_window_attn_bwd_h", _chk(qkv, BF16, (M, 48 * heads), "qkv"), _chk(gout, BF16, (M, 16 * heads), "gout"),
               _chk(bias_t, F32, (heads, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (heads, 4, 4, 64, 4), "bias_n"),
               gqkv.data_ptr(), dbias.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
@@ -725,7 +757,7 @@ def wt_patch_wgrad(p, fmap):
     """fp32 [NI][4096] = p^T patches(fmap); p fp32 window-layout tokens [M][NI] over the floor(H/8) x floor(W/8) grid."""
     B, H, W, C = fmap.shape
     NI = p.shape[1]
-    out = torch.zeros((NI, 4096), dtype=F32, device=p.device)
+    out = _zeros((NI, 4096), p.device)
     _lib.call("tup_wt_patch_wgrad", _chk(p, F32, None, "p"), _chk(fmap, BF16, None, "map"), out.data_ptr(), B, H, W, NI, _stream())
     return out
 

@@ -177,6 +177,10 @@ int tup_rt_bicubic_sum_fwd(const float* a, const float* b, float* out, const int
  * 1 = fp32.  For nn.Linear: P = grad_output, Q = input -> out = weight.grad layout [out][in]. */
 int tup_gemm_wgrad(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
                    float* out, int ldo, int M, int NI, int NJ, void* stream);
+/* The same with the layer's bias gradient in the same pass (model.py:79,81,146-151 under train.py:138):
+ * colsum_out[NI] (fp32, zeroed by the caller) += column sums of P. */
+int tup_gemm_wgrad_bias(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
+                        float* out, int ldo, float* colsum_out, int M, int NI, int NJ, void* stream);
 
 /* Weight gradient of patch_embed (reflect=1: P = grad tokens, map = feat) and of patch_unembed
  * (reflect=0: P = tokens, map = grad of its output).  out fp32 [192][4096] +=, column (i*8+j)*64+c. */

@@ -183,6 +183,11 @@ def test_gemm_wgrad_and_colsum(dev, M, NI, NJ, pd, qd):
     close(got, ref, 2e-3 * (M ** 0.5), 1e-3, "wgrad")
     src = P.to(dt[pd])
     close(ops.colsum(src.to(dev)), src.float().sum(0), 1e-3, 1e-4, "colsum")
+    # weight and bias gradient in one pass: the column sums ride on an MFMA against a ones operand (bf16 rounding of an
+    # fp32 P happens before the sum, as for the weight gradient)
+    gw, gb = ops.gemm_wgrad_bias(P.to(dt[pd]).to(dev), Q.to(dt[qd]).to(dev))
+    close(gw, ref, 2e-3 * (M ** 0.5), 1e-3, "wgrad (fused)")
+    close(gb, bf(P).sum(0), 2e-3 * (M ** 0.5), 1e-3, "bias grad (fused)")
 
 
 def test_gemm_gelu_bwd_and_fp32_a(dev):

@@ -64,6 +64,7 @@ SIGNATURES = {
     "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],
     # backward
     "tup_gemm_wgrad": [P, I, I, P, I, I, P, I, I, I, I, P],
+    "tup_gemm_wgrad_bias": [P, I, I, P, I, I, P, I, P, I, I, I, P],
     "tup_patch_wgrad": [P, P, P, I, I, I, I, P],
     "tup_colsum": [P, I, I, P, I, I, P, P],
     "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],

@@ -144,25 +144,21 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None) -> Dict[
         s, p = sv["blocks"][i], f"window_blocks.{i}"
         # gradient entering mlp.2's output: through the MLP dropout mask (the residual path keeps g_x itself)
         g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
-        g[p + ".mlp.2.bias"] = ops.colsum(g_o)
-        g[p + ".mlp.2.weight"] = ops.gemm_wgrad(g_o, s["hid"])
+        g[p + ".mlp.2.weight"], g[p + ".mlp.2.bias"] = ops.gemm_wgrad_bias(g_o, s["hid"])
         g_h = ops.gemm_tokens(g_o, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
         del g_o
-        g[p + ".mlp.0.bias"] = ops.colsum(g_h)
-        g[p + ".mlp.0.weight"] = ops.gemm_wgrad(g_h, s["y2"])
+        g[p + ".mlp.0.weight"], g[p + ".mlp.0.bias"] = ops.gemm_wgrad_bias(g_h, s["y2"])
         g_y2 = ops.gemm_tokens(g_h, pk[f"b{i}.fc1.wd"], None, "bf16")
         del g_h
         g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"] = ops.layernorm_bwd(
             g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
         g_o = ops.dropout_bwd(g_xm, drop_p, site_seed(seed, i, 1)) if drop_p > 0 else g_xm      # proj_drop
-        g[p + ".attn.proj.bias"] = ops.colsum(g_o)
-        g[p + ".attn.proj.weight"] = ops.gemm_wgrad(g_o, s["att"])
+        g[p + ".attn.proj.weight"], g[p + ".attn.proj.bias"] = ops.gemm_wgrad_bias(g_o, s["att"])
         g_att = ops.gemm_tokens(g_o, pk[f"b{i}.proj.wd"], None, "bf16")
         del g_o
         g_qkv, g[p + ".attn.relative_position_bias_table"] = ops.window_attn_bwd(
             s["qkv"], g_att, frags_t[i], frags_n[i], drop_p, site_seed(seed, i, 0))
-        g[p + ".attn.qkv.bias"] = ops.colsum(g_qkv)
-        g[p + ".attn.qkv.weight"] = ops.gemm_wgrad(g_qkv, s["y1"])
+        g[p + ".attn.qkv.weight"], g[p + ".attn.qkv.bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.qkv.wd"], None, "bf16")
         del g_qkv, g_att
         g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm_bwd(

@@ -81,22 +81,18 @@ def backward_train(pk, sv, gout, reducer=None) -> Dict[str, torch.Tensor]:
     for i in reversed(range(pk["nblocks"])):
         s, p = sv["blocks"][i], f"transformer_blocks.{i}"
         g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
-        g[p + ".mlp.2.bias"] = ops.colsum(g_o)
-        g[p + ".mlp.2.weight"] = ops.gemm_wgrad(g_o, s["hid"])
+        g[p + ".mlp.2.weight"], g[p + ".mlp.2.bias"] = ops.gemm_wgrad_bias(g_o, s["hid"])
         g_h = ops.gemm_tokens(g_o, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
         del g_o
-        g[p + ".mlp.0.bias"] = ops.colsum(g_h)
-        g[p + ".mlp.0.weight"] = ops.gemm_wgrad(g_h, s["y2"])
+        g[p + ".mlp.0.weight"], g[p + ".mlp.0.bias"] = ops.gemm_wgrad_bias(g_h, s["y2"])
         g_y2 = ops.gemm_tokens(g_h, pk[f"b{i}.fc1.wd"], None, "bf16")
         del g_h
         g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"] = ops.layernorm128_bwd(
             g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
-        g[p + ".attn.out_proj.bias"] = ops.colsum(g_xm)
-        g[p + ".attn.out_proj.weight"] = ops.gemm_wgrad(g_xm, s["att"])
+        g[p + ".attn.out_proj.weight"], g[p + ".attn.out_proj.bias"] = ops.gemm_wgrad_bias(g_xm, s["att"])
         g_att = ops.gemm_tokens(g_xm, pk[f"b{i}.out.wd"], None, "bf16")
         g_qkv = ops.rt_attention_bwd(s["qkv"], s["att"], g_att, s["lse"], B, N, drop_p=drop_p, drop_seed=site_seed(seed, i, 0))
-        g[p + ".attn.in_proj_bias"] = ops.colsum(g_qkv)
-        g[p + ".attn.in_proj_weight"] = ops.gemm_wgrad(g_qkv, s["y1"])
+        g[p + ".attn.in_proj_weight"], g[p + ".attn.in_proj_bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.in.wd"], None, "bf16")
         del g_qkv, g_att
         g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm128_bwd(

@@ -20,6 +20,7 @@ struct WgradParams {
     const void* P; int ldp;      // [M][NI] bf16 or fp32
     const void* Q; int ldq;      // [M][NJ] bf16 / fp32, or NHWC bf16 map for OP_PATCH
     float* out; int ldo;         // [NI][NJ] fp32, accumulated
+    float* colsum_out;           // optional [NI] fp32, accumulated: column sums of P (the layer's bias gradient)
     int M, NI, NJ, mchunk;
     int H, W, Ht, Wt_, nWx, nWy, reflect;   // OP_PATCH geometry (token rows in window layout)
     int linear;                             // OP_PATCH: token rows are a plain [B][Ht][Wt] grid (ResidualTransformer)
@@ -114,6 +115,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
     f32x4 acc[4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of P: the workgroups of the first column block also multiply their P fragments by a
+    // ones operand (one more MFMA per K-step there) instead of a separate pass over P (tup_colsum)
+    const bool want_cs = p.colsum_out != nullptr && blockIdx.y == 0;
+    f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
     // transposed-read addressing: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
     const int trq = l16 >> 2, trp = l16 & 3;
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
                                         lds_read_tr16(qb + swz128(row + 4, qcol >> 3) + (qcol & 7) * 2));
                 acc[jt] = mfma16x16x32(af, bfr, acc[jt]);
             }
+            if (want_cs) accs = mfma16x16x32(af, ones, accs);
         }
         if (s + 1 < nsteps) store_stage(buf ^ 1);
         __syncthreads();
@@ -156,6 +163,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             atomicAdd(p.out + (size_t)(i0 + 16 * wave + 4 * g + e) * p.ldo + j0 + 16 * jt + l16, acc[jt][e]);
+    if (want_cs && l16 == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(p.colsum_out + i0 + 16 * wave + 4 * g + e, accs[e]);
+    }
 }
 
 // column sums: out[n] += sum_m G[m][n].  16-byte loads: LPR lanes cover a 64-column stripe of one row, the
@@ -218,12 +229,24 @@ int launch(WgradParams p, hipStream_t s)
 
 }  // namespace
 
+// out[NI][NJ] (fp32, ldo) += P^T Q and, when colsum_out != NULL, colsum_out[NI] += column sums of P (weight and bias
+// gradient of a Linear layer in one pass over grad_out).  p_dtype / q_dtype: 0 = bf16, 1 = fp32.  The caller zeroes both.
+extern "C" int tup_gemm_wgrad_bias(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
+                                   float* out, int ldo, float* colsum_out, int M, int NI, int NJ, void* stream);
+
 // out[NI][NJ] (fp32, ldo) += P^T Q.  p_dtype / q_dtype: 0 = bf16, 1 = fp32.  The caller zeroes `out`.
 extern "C" int tup_gemm_wgrad(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
                               float* out, int ldo, int M, int NI, int NJ, void* stream)
 {
+    return tup_gemm_wgrad_bias(P, p_dtype, ldp, Q, q_dtype, ldq, out, ldo, nullptr, M, NI, NJ, stream);
+}
+
+extern "C" int tup_gemm_wgrad_bias(const void* P, int p_dtype, int ldp, const void* Q, int q_dtype, int ldq,
+                                   float* out, int ldo, float* colsum_out, int M, int NI, int NJ, void* stream)
+{
     WgradParams p{};
     p.P = P; p.ldp = ldp; p.Q = Q; p.ldq = ldq; p.out = out; p.ldo = ldo; p.M = M; p.NI = NI; p.NJ = NJ;
+    p.colsum_out = colsum_out;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (p_dtype == 0 && q_dtype == 0) return launch<OP_BF16, OP_BF16>(p, s);
     if (p_dtype == 1 && q_dtype == 0) return launch<OP_F32, OP_BF16>(p, s);

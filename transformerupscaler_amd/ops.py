@@ -327,6 +327,19 @@ def gemm_wgrad(p, q, out=None):
     return out
 
 
+def gemm_wgrad_bias(p, q):
+    """(dW [NI][NJ], db [NI]) = (p^T q, column sums of p): weight and bias gradient of a Linear layer in one pass over p."""
+    M, NI = p.shape
+    NJ = q.shape[1]
+    assert q.shape[0] == M and NI % 64 == 0 and NJ % 64 == 0
+    out = _zeros((NI, NJ), p.device)
+    db = _zeros((NI,), p.device)
+    _lib.call("tup_gemm_wgrad_bias", _chk(p, p.dtype, None, "p"), {BF16: 0, F32: 1}[p.dtype], NI,
+              _chk(q, q.dtype, None, "q"), {BF16: 0, F32: 1}[q.dtype], NJ, out.data_ptr(), NJ, db.data_ptr(),
+              M, NI, NJ, _stream())
+    return out, db
+
+
 def patch_wgrad(p, fmap, reflect):
     B, H, W, C = fmap.shape
     _, _, nwy, nwx = window_geometry(H, W)

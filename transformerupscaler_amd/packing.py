@@ -82,6 +82,20 @@ def pack_linear(weight: torch.Tensor):
     return perm_rows64(weight).contiguous().to(torch.bfloat16)
 
 
+def pack_linear_stack(weights, transpose: bool = False):
+    """pack_linear of several same-shaped nn.Linear weights with three launches in all (stack, row gather, bf16 cast)
+    instead of two or three per weight: the training loop repacks every weight after every optimizer step, and ~150 tiny
+    launches per step were a measurable slice of it.  transpose=True packs W^T (the input-gradient GEMM's operand).
+    Returns one bf16 [n][rows][cols] tensor; entry i is contiguous."""
+    w = torch.stack([t.detach() for t in weights])                     # [n][N][K]
+    if transpose:
+        w = w.transpose(1, 2)                                          # view; the gather below writes it out contiguous
+    n = w.shape[1]
+    assert n % 64 == 0
+    idx = _dev_index(("rows64", n), lambda: (torch.arange(n // 64).view(-1, 1) * 64 + _PERM64.view(1, -1)).reshape(-1), w.device)
+    return w.index_select(1, idx).to(torch.bfloat16)
+
+
 def pack_fc1_fused(weight: torch.Tensor):
     """mlp.0 weight for tup_fused_mlp_fwd: pack_linear plus a column permutation.  K-step st of the kernel's FC1, lane
     group g, element j contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j -- the channels whose residual the same
@@ -227,8 +241,16 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
             pk[f"b{i}.{nm}.w"] = f32(sd[f"{p}.{nm}.weight"]); pk[f"b{i}.{nm}.b"] = f32(sd[f"{p}.{nm}.bias"])
         pk[f"b{i}.table"] = f32(sd[f"{p}.attn.relative_position_bias_table"])
         for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
-            pk[f"b{i}.{nm}.w"] = pack_linear(sd[f"{p}.{key}.weight"].detach())
             pk[f"b{i}.{nm}.b"] = f32(sd[f"{p}.{key}.bias"])
+    for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
+        ws = [sd[f"window_blocks.{i}.{key}.weight"] for i in range(BLOCKS)]
+        wp = pack_linear_stack(ws)
+        for i in range(BLOCKS):
+            pk[f"b{i}.{nm}.w"] = wp[i]
+        if backward:
+            wt = pack_linear_stack(ws, transpose=True)
+            for i in range(BLOCKS):
+                pk[f"b{i}.{nm}.wd"] = wt[i]
     if not backward:      # inference fusion of norm1 + qkv + attention
         for i in range(BLOCKS):
             pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"window_blocks.{i}.attn.qkv.weight"], sd[f"window_blocks.{i}.attn.qkv.bias"])
@@ -251,10 +273,6 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         pk[f"fu.{si}.raw"] = f32(sd[f"final_upscale.upsamplers.{scale}.{idx}.weight"])
     pk["pe.wd"] = pack_linear(t("patch_embed.weight").permute(2, 3, 1, 0).reshape(4096, 192))     # rows (i,j,c), cols n
     pk["pu.wd"] = pack_linear(t("patch_unembed.weight").permute(0, 2, 3, 1).reshape(192, 4096))   # rows k, cols (i,j,o)
-    for i in range(BLOCKS):
-        p = f"window_blocks.{i}"
-        for nm, key in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.0"), ("fc2", "mlp.2")):
-            pk[f"b{i}.{nm}.wd"] = pack_linear(t(f"{p}.{key}.weight").t().contiguous())
     return pk
 
 

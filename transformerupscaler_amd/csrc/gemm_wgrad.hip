@@ -11,6 +11,7 @@
 //   patch_embed weight    model.py:215,268          P = grad tokens, Q = 8x8 patches of feat (gather)
 //   patch_unembed weight  model.py:225,302          P = tokens, Q = 8x8 patches of grad map (gather)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,6 +25,7 @@ struct WgradParams {
     int M, NI, NJ, mchunk;
     int H, W, Ht, Wt_, nWx, nWy, reflect;   // OP_PATCH geometry (token rows in window layout)
     int linear;                             // OP_PATCH: token rows are a plain [B][Ht][Wt] grid (ResidualTransformer)
+    int xcd_remap;
 };
 
 TUP_DEVICE s16x4 lds_read_tr16(const char* p) {
@@ -36,8 +38,20 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];   // [buf][P|Q][64 rows][128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
-    const int mbeg = blockIdx.z * p.mchunk;
+    // XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, and
+    // the gridDim.x * gridDim.y blocks of one M slice all read the same rows of P and Q: in launch order those blocks
+    // land on all 8 XCDs and every L2 fetches the slice for itself.  Renumber so that XCD k works through a contiguous
+    // range of logical blocks (same M slice = same XCD).
+    const int T = gridDim.x * gridDim.y * gridDim.z;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int Lp = L;
+    if (p.xcd_remap) {
+        const int xcd = L & 7, slot = L >> 3, base = T >> 3, rem = T & 7;
+        Lp = xcd * base + min(xcd, rem) + slot;
+    }
+    const int bx = Lp % gridDim.x, by = (Lp / gridDim.x) % gridDim.y, bz = Lp / (gridDim.x * gridDim.y);
+    const int i0 = bx * 64, j0 = by * 64;
+    const int mbeg = bz * p.mchunk;
     const int mend = min(p.M, mbeg + p.mchunk);
     if (mbeg >= mend) return;
     const int nsteps = (mend - mbeg + 63) / 64;
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
     for (int jt = 0; jt < 4; ++jt) acc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bias gradient = column sums of P: the workgroups of the first column block also multiply their P fragments by a
     // ones operand (one more MFMA per K-step there) instead of a separate pass over P (tup_colsum)
-    const bool want_cs = p.colsum_out != nullptr && blockIdx.y == 0;
+    const bool want_cs = p.colsum_out != nullptr && by == 0;
     f32x4 accs = {0.f, 0.f, 0.f, 0.f};
     const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 
@@ -222,6 +236,8 @@ int launch(WgradParams p, hipStream_t s)
     if (msplit < 1) msplit = 1;
     p.mchunk = (((p.M + msplit - 1) / msplit) + 63) / 64 * 64;
     msplit = (p.M + p.mchunk - 1) / p.mchunk;
+    static const int remap = getenv("TUP_WGRAD_NO_XCD") ? 0 : 1;            // A/B switch
+    p.xcd_remap = remap;
     gemm_wgrad_kernel<PMODE, QMODE><<<dim3(p.NI / 64, p.NJ / 64, msplit), dim3(256), 0, s>>>(p);
     TUP_CHECK_LAUNCH();
     return 0;

@@ -11,6 +11,7 @@
 //   patch_embed weight    model.py:215,268          P = grad tokens, Q = 8x8 patches of feat (gather)
 //   patch_unembed weight  model.py:225,302          P = tokens, Q = 8x8 patches of grad map (gather)
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -58,20 +59,28 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
 
     // staging: thread -> chunk (tid&7) of rows (tid>>3) and (tid>>3)+32
     const int chunk = tid & 7;
-    u32x4 preg[(PMODE == OP_F32) ? 4 : 2], qreg[(QMODE == OP_F32) ? 4 : 2];
+    // two register sets: tile s+2 is requested while tile s is multiplied and tile s+1 waits in the other set -- with one set
+    // a step (8 MFMAs per wave) was shorter than the global round trip it had to cover
+    u32x4 pregs[2][(PMODE == OP_F32) ? 4 : 2], qregs[2][(QMODE == OP_F32) ? 4 : 2];
+    unsigned okm[2] = {0u, 0u};              // validity of a set's four loads: bit 2u = P row u, bit 2u+1 = Q row u
 
-    auto load_plain = [&](const void* base, int ld, int col0, int m, bool f32, u32x4* r) {
+    // Loads are unconditional (clamped address, value zeroed afterwards): a predicated load compiles to a branch around it,
+    // and with branches in the stream hipcc falls back to s_waitcnt vmcnt(0) everywhere -- which makes the wait for the
+    // older register set also a wait for the set requested a moment ago.
+    // (the zeroing happens at the LDS store, a full step later: a select right behind the load would wait for it at once)
+    auto load_plain = [&](const void* base, int ld, int col0, int m, bool f32, u32x4* r) -> bool {
         const bool ok = m < mend;
+        const int mc = ok ? m : mend - 1;
         if (!f32) {
-            r[0] = ok ? *reinterpret_cast<const u32x4*>((const bf16_t*)base + (size_t)m * ld + col0 + chunk * 8)
-                      : u32x4{0u, 0u, 0u, 0u};
+            r[0] = *reinterpret_cast<const u32x4*>((const bf16_t*)base + (size_t)mc * ld + col0 + chunk * 8);
         } else {
-            const float* s = (const float*)base + (size_t)m * ld + col0 + chunk * 8;
-            r[0] = ok ? *reinterpret_cast<const u32x4*>(s) : u32x4{0u, 0u, 0u, 0u};
-            r[1] = ok ? *reinterpret_cast<const u32x4*>(s + 4) : u32x4{0u, 0u, 0u, 0u};
+            const float* s = (const float*)base + (size_t)mc * ld + col0 + chunk * 8;
+            r[0] = *reinterpret_cast<const u32x4*>(s);
+            r[1] = *reinterpret_cast<const u32x4*>(s + 4);
         }
+        return ok;
     };
-    auto load_patch = [&](int m, u32x4* r) {
+    auto load_patch = [&](int m, u32x4* r) -> bool {
         // column block j0 = patch pixel (i, j); 64 channels
         bool ok = m < mend;
         int b, ty, tx;
@@ -97,17 +106,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
         } else {
             ok = ok && py < p.H && px < p.W;
         }
-        r[0] = ok ? *reinterpret_cast<const u32x4*>((const bf16_t*)p.Q + (((size_t)b * p.H + py) * p.W + px) * 64 + chunk * 8)
-                  : u32x4{0u, 0u, 0u, 0u};
+        const size_t off = ok ? (((size_t)b * p.H + py) * p.W + px) * 64 : 0;           // pixel 0 of the map when masked
+        r[0] = *reinterpret_cast<const u32x4*>((const bf16_t*)p.Q + off + chunk * 8);
+        return ok;
     };
-    auto load_stage = [&](int s) {
+    auto load_stage = [&](int s, u32x4* preg, u32x4* qreg, unsigned& ok) {
+        ok = 0u;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int m = mbeg + s * 64 + (tid >> 3) + 32 * u;
             constexpr int PS = (PMODE == OP_F32) ? 2 : 1, QS = (QMODE == OP_F32) ? 2 : 1;
-            load_plain(p.P, p.ldp, i0, m, PMODE == OP_F32, &preg[u * PS]);
-            if constexpr (QMODE == OP_PATCH) load_patch(m, &qreg[u * QS]);
-            else load_plain(p.Q, p.ldq, j0, m, QMODE == OP_F32, &qreg[u * QS]);
+            if (load_plain(p.P, p.ldp, i0, m, PMODE == OP_F32, &preg[u * PS])) ok |= 1u << (2 * u);
+            bool qok;
+            if constexpr (QMODE == OP_PATCH) qok = load_patch(m, &qreg[u * QS]);
+            else qok = load_plain(p.Q, p.ldq, j0, m, QMODE == OP_F32, &qreg[u * QS]);
+            if (qok) ok |= 2u << (2 * u);
         }
     };
     auto cvt = [&](const u32x4* r, bool f32) -> u32x4 {
@@ -115,14 +128,15 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
         const f32x4 lo = __builtin_bit_cast(f32x4, r[0]), hi = __builtin_bit_cast(f32x4, r[1]);
         return u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, const u32x4* preg, const u32x4* qreg, unsigned ok) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int row = (tid >> 3) + 32 * u;
             constexpr int PS = (PMODE == OP_F32) ? 2 : 1, QS = (QMODE == OP_F32) ? 2 : 1;
             char* base = smem + buf * (2 * 64 * 128);
-            *reinterpret_cast<u32x4*>(base + swz128(row, chunk)) = cvt(&preg[u * PS], PMODE == OP_F32);
-            *reinterpret_cast<u32x4*>(base + 64 * 128 + swz128(row, chunk)) = cvt(&qreg[u * QS], QMODE == OP_F32);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(base + swz128(row, chunk)) = ((ok >> (2 * u)) & 1u) ? cvt(&preg[u * PS], PMODE == OP_F32) : z;
+            *reinterpret_cast<u32x4*>(base + 64 * 128 + swz128(row, chunk)) = ((ok >> (2 * u + 1)) & 1u) ? cvt(&qreg[u * QS], QMODE == OP_F32) : z;
         }
     };
 
@@ -138,12 +152,17 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
     // transposed-read addressing: lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3
     const int trq = l16 >> 2, trp = l16 & 3;
 
-    load_stage(0);
-    store_stage(0);
+    load_stage(0, pregs[0], qregs[0], okm[0]);
+    load_stage(min(1, nsteps - 1), pregs[1], qregs[1], okm[1]);
+    store_stage(0, pregs[0], qregs[0], okm[0]);
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
+    // step s: LDS buffer s & 1 holds tile s; register set (s + 1) & 1 holds tile s + 1; set s & 1 is free
+    auto step = [&](const int s, auto setc) {
+        constexpr int FREE = decltype(setc)::value;          // = s & 1
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_stage(s + 1);
+        // unconditional (the last two steps re-request the last tile): a load under a branch makes hipcc assume the
+        // smaller in-flight count at the join and wait for the new loads as well
+        load_stage(min(s + 2, nsteps - 1), pregs[FREE], qregs[FREE], okm[FREE]);
         const char* pb = smem + buf * (2 * 64 * 128);
         const char* qb = pb + 64 * 128;
         // two K-steps of 32 rows on v_mfma_f32_16x16x32_bf16 (the 16x16x16 form runs at half its rate on gfx950):
@@ -167,8 +186,12 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
             }
             if (want_cs) accs = mfma16x16x32(af, ones, accs);
         }
-        if (s + 1 < nsteps) store_stage(buf ^ 1);
+        if (s + 1 < nsteps) store_stage(buf ^ 1, pregs[FREE ^ 1], qregs[FREE ^ 1], okm[FREE ^ 1]);
         __syncthreads();
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nsteps) step(s + 1, std::integral_constant<int, 1>{});
     }
 
     // D[row = i 4g+e][col = j l16]

@@ -55,16 +55,32 @@ __global__ __launch_bounds__(256, (CT <= 4 && KS == 3) ? 2 : 1) void conv3x3_c64
     const int nci = in_r * in_r;
     const int Hin = H * in_r, Win = W * in_r;
     const bf16_t* xb = x + (size_t)b * Hin * Win * 64;
+    // All of a thread's halo loads are issued before any is stored (unconditional loads from a clamped address, zeroed at
+    // the store): the rolled load -> store loop paid one global round trip per iteration, eleven per staged chunk.
+    constexpr int NSI = (NPIX_HALO * 8 + 255) / 256;
     auto stage_input = [&](int ci) {
         const int si = ci / in_r, sj = ci - si * in_r;
-        for (int idx = tid; idx < NPIX_HALO * 8; idx += 256) {
-            const int q = idx >> 3, c = idx & 7;
+        u32x4 v[NSI];
+        auto pos = [&](int idx, int& q, int& c, size_t& off) -> bool {
+            q = idx >> 3; c = idx & 7;
             const int yy = q / HALO_W, xx = q - yy * HALO_W;
             const int iy = ty0 - PADK + yy, ix = tx0 - PADK + xx;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                v = *reinterpret_cast<const u32x4*>(xb + ((size_t)(iy * in_r + si) * Win + (ix * in_r + sj)) * 64 + c * 8);
-            *reinterpret_cast<u32x4*>(in_lds + swz128(q, c)) = v;
+            const bool ok = idx < NPIX_HALO * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            off = ok ? ((size_t)(iy * in_r + si) * Win + (ix * in_r + sj)) * 64 + c * 8 : 0;
+            return ok;
+        };
+#pragma unroll
+        for (int k = 0; k < NSI; ++k) {
+            int q, c; size_t off;
+            pos(tid + k * 256, q, c, off);
+            v[k] = *reinterpret_cast<const u32x4*>(xb + off);
+        }
+#pragma unroll
+        for (int k = 0; k < NSI; ++k) {
+            const int idx = tid + k * 256;
+            int q, c; size_t off;
+            const bool ok = pos(idx, q, c, off);
+            if (idx < NPIX_HALO * 8) *reinterpret_cast<u32x4*>(in_lds + swz128(q, c)) = ok ? v[k] : u32x4{0u, 0u, 0u, 0u};
         }
     };
     stage_input(0);

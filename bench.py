@@ -7,13 +7,18 @@ are already resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Inference shards by images with no data-path collective (replicas, weak scaling).  Prints ONE JSON
-line on rank 0 (contract in the task statement), including the roofline of the dominant kernel
-(the 64->64 3x3 implicit-GEMM conv, MFMA-bound; since the branch-A composition the 64->256 up-conv no
-longer runs at inference) measured live with events on the launch stream, and the CPU
-baseline (the oracle = CPU restatement of the reference, "port") on a bounded sample.
+line on rank 0 (contract in the task statement).  ``roofline`` describes the kernel with the largest
+total time per forward, decided live from event timings on the launch stream: the whole-block kernel
+``fused_qkv_attn_kernel<true,true>`` (one launch per WindowTransformerBlock, 6 per forward; algorithmic
+FLOPs = the window-attention GEMM set of SURVEY 8(d), 86.1 GF per image / 6) or the 64->64 3x3
+implicit-GEMM conv (conv2 + decoder_conv1, 2 launches per forward); the other one is reported as
+``roofline_second``.  ``cpu_baseline`` = the oracle (CPU restatement of the reference, "port") on a
+bounded sample: forward, forward+backward (train.py:117-140), and the PSNR of the build's output
+against the oracle's output for the same image (``psnr_vs_ref_db``, plus ΔPSNR against a synthetic HR).
 """
 import argparse
 import contextlib
+import hashlib
 import json
 import os
 import sys
@@ -30,28 +35,101 @@ CONV64_FLOP_PER_IMAGE = 2.0 * LR_H * LR_W * 64 * 576
 ATTN_SET_FLOP_PER_IMAGE = 86.1e9                            # window-attention GEMM set (qkv, QK^T, PV, proj, fc1, fc2)
 
 
-def cpu_baseline(batch_images: int):
-    """Oracle (CPU restatement of the reference path) on the host cores, B=1, same synthetic input."""
-    from oracle import fast_transformer_oracle as O
-    from transformerupscaler_amd.weights import deterministic_state_dict
+def _cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("TUP_CPU_THREADS", "16")))     # the 1-GPU box's CPU share is 16
+    return min(cores, int(os.environ.get("TUP_CPU_THREADS", "16")))     # the 1-GPU box's CPU share is 16
+
+
+def _psnr(a, b):
+    import math
+    mse = ((a.double() - b.double()) ** 2).mean().item()
+    return 99.0 if mse == 0 else 10 * math.log10(1.0 / mse)
+
+
+def cpu_baseline(model, dev):
+    """Oracle (CPU restatement of the reference path) on the host cores, B=1, same synthetic input; its output doubles as
+    the fidelity reference for the build's output on that image."""
+    from oracle import fast_transformer_oracle as O
+    from transformerupscaler_amd.weights import deterministic_state_dict
+    cores = _cores()
     torch.set_num_threads(cores)
     sd = deterministic_state_dict(0)
-    x = torch.rand((1, 3, LR_H, LR_W), generator=torch.Generator().manual_seed(1234))
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand((1, 3, LR_H, LR_W), generator=g)
+    hr = torch.rand((1, 3) + OUT, generator=g)
     with torch.no_grad():
-        O.forward(sd, x, res_out=OUT)                 # warm-up
+        y_ref = O.forward(sd, x, res_out=OUT)                 # warm-up (and the fidelity reference)
         n, t0 = 0, time.time()
-        while n < 3 or (time.time() - t0 < 10.0 and n < 8):
+        while n < 3 or (time.time() - t0 < 8.0 and n < 8):
             O.forward(sd, x, res_out=OUT)
             n += 1
         dt = time.time() - t0
+        y = model(x.to(dev), res_out=OUT).cpu()
+    # forward + backward of one train.py step (train.py:117-140: res_out = HR size, require_ratio=False, Resize, L1)
+    gt = torch.Generator().manual_seed(4321)
+    lr1 = torch.rand((1, 3, LR_H, LR_W), generator=gt)
+    hr1 = torch.rand((1, 3) + OUT, generator=gt)
+    O.train_step_grads(sd, lr1, hr1)                          # warm-up
+    m, t1 = 0, time.time()
+    while m < 2:
+        O.train_step_grads(sd, lr1, hr1)
+        m += 1
+    dtt = time.time() - t1
+    base = {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} forward passes of 1 image 720x1280 -> 1080x1920 fp32 after 1 warm-up (torch CPU, {cores} threads)",
+            "train_value": m / dtt, "train_sample": f"{m} forward+backward passes (train.py:117-140 step without Adam, L1 loss, dropout off) "
+                                                    f"of 1 image after 1 warm-up, fp32, {cores} threads"}
+    fidelity = {"psnr_vs_ref_db": _psnr(y, y_ref), "max_abs_vs_ref": (y - y_ref).abs().max().item(),
+                "psnr_vs_hr_build_db": _psnr(y, hr), "psnr_vs_hr_ref_db": _psnr(y_ref, hr),
+                "delta_psnr_vs_hr_db": _psnr(y, hr) - _psnr(y_ref, hr),
+                "sample": "image 0 of the synthetic set (seed 1234), 720x1280 -> 1080x1920; HR = seeded uniform noise, so the absolute "
+                          "PSNR-vs-HR is meaningless and only its difference (target <= 0.01 dB) is read"}
+    return base, fidelity
+
+
+def rt_cpu_baseline():
+    """ResidualTransformer x6 training graph (forward + backward, L1) of the oracle on the host cores, one image."""
+    from oracle import residual_transformer_oracle as R
+    from transformerupscaler_amd.weights import rt_deterministic_state_dict
+    import torch.nn.functional as F
+    cores = _cores()
+    torch.set_num_threads(cores)
+    sd = rt_deterministic_state_dict(0)
+    g = torch.Generator().manual_seed(9876)
+    lr = torch.rand((1, 3, LR_H, LR_W), generator=g)
+    hr = torch.rand((1, 3, LR_H * 6, LR_W * 6), generator=g)
+
+    def step():
+        leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        F.l1_loss(R.forward(leaf, lr, upscale_factor=6), hr).backward()
+
+    step()
+    n, t0 = 0, time.time()
+    while n < 2:
+        step(); n += 1
+    dt = time.time() - t0
     return {"value": n / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} forward passes of 1 image 720x1280 -> 1080x1920 fp32 after 1 warm-up (torch CPU, {cores} threads)"}
+            "sample": f"{n} forward+backward passes of 1 image 720x1280 -> 4320x7680 fp32 (L1 loss, dropout off) after 1 warm-up"}
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch from the committed PMC run of this round, or None when the kernel's source changed since
+    (the JSON records the sha256 of the .hip file it was measured on; a stale number is worse than none)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            pm = json.load(f)
+        ent = pm[kernel_key]
+        with open(os.path.join(ROOT, "transformerupscaler_amd", "csrc", ent["source"]), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+        if sha != ent["source_sha256"]:
+            return None, f"stale: {ent['source']} changed since profiles/r02_pmc_traffic.json was measured"
+        return ent["traffic_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+    except Exception as e:          # noqa: BLE001
+        return None, f"unavailable ({type(e).__name__})"
 
 
 def main():
@@ -62,8 +140,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="inference images per GPU per step")
     ap.add_argument("--train-batch", type=int, default=4, help="training images per GPU per step (config 3: 32 / 8 GPUs)")
     ap.add_argument("--rt-batch", type=int, default=2, help="ResidualTransformer 6x training images per GPU per step (config 5: 16 / 8 GPUs)")
-    ap.add_argument("--mode", choices=["infer", "train", "rt", "both"], default="both",
-                    help="both = headline inference + FastTransformer training step + ResidualTransformer 6x training step")
+    ap.add_argument("--x4-batch", type=int, default=4, help="config 4 (4x 540p -> 2160p inference) images per GPU per step")
+    ap.add_argument("--mode", choices=["infer", "train", "rt", "x4", "both"], default="both",
+                    help="both = headline inference + 4x 540p inference (config 4) + FastTransformer training step + "
+                         "ResidualTransformer 6x training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -187,6 +267,48 @@ def main():
                 "parallelism": f"dp{world}" + (" RCCL all-reduce of 12.8 MB fp32 grads, overlapped with backward" if world > 1 else ""),
                 "optimizer": "Adam lr 1e-4 (torch.optim)", "loss_fn": "L1 vs synthetic 4320x7680 HR"}
 
+    def run_x4():
+        """BASELINE.json configs[3]: 4x 540x960 -> 2160x3840 bf16 inference, batch 4 per GPU (two-stage branch A: explicit
+        64->256 conv + PixelShuffle at 540p, then the composed 5x5 at 1080p; reflect-padded 544-row token grid)."""
+        gx = torch.Generator().manual_seed(777 + rank)
+        xx = torch.rand((args.x4_batch, 3, 540, 960), generator=gx).to(dev)
+        steps = max(1, min(args.steps, 10))
+        with torch.no_grad():
+            for _ in range(3):
+                model(xx, upscale_factor=4)
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                yy = model(xx, upscale_factor=4)
+            torch.cuda.synchronize()
+            barrier()
+            dtt = time.perf_counter() - t0
+        assert tuple(yy.shape) == (args.x4_batch, 3, 2160, 3840)
+        if dist is not None:
+            t = torch.tensor([dtt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtt = float(t.item())
+        flop = 950.2e9 * args.x4_batch                      # SURVEY 8(d): 950.2 GF forward per image as the reference computes it
+        return {"metric": "images/sec, FastTransformer 4x 540p->2160p inference", "value": world * args.x4_batch * steps / dtt,
+                "unit": "images/sec", "ms_per_step": dtt / steps * 1e3, "steps": steps, "images_per_gpu_per_step": args.x4_batch,
+                "reference_gflop_per_image": 950.2,
+                "reference_flop_rate_tflops": flop / (dtt / steps) / 1e12,
+                "note": "reference-FLOP rate = the reference's 950.2 GF per image / time; the build executes fewer (the last up-conv + "
+                        "PixelShuffle + up1_conv run as one composed 5x5 conv)"}
+
+    x4_result = run_x4() if args.mode in ("x4", "both") else None
+    if args.mode == "x4":
+        if rank == 0:
+            out = dict(x4_result)
+            out.update({"n_gpus": world, "warmup": 3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                        "dtype": "bf16", "data": "synthetic",
+                        "config": {"workload": "FastTransformer 4x 540x960 -> 2160x3840 bf16 inference (BASELINE.json configs[3])"}})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     train_result = run_train() if args.mode in ("train", "both") else None
     rt_result = run_rt_train() if args.mode in ("rt", "both") else None
     if args.mode == "rt":
@@ -231,18 +353,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    traffic = None       # HBM bytes per launch of the dominant kernel from a committed PMC run (profiles/), not measured live
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv64.json")) as f:
-            pm = json.load(f)
-        if args.batch == 8:
-            traffic = pm["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    kern_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)
-    blocks_ms = sum(s.elapsed_time(e) for s, e in block_events) / max(len(block_events), 1)
-    attn_set_tf = ATTN_SET_FLOP_PER_IMAGE * args.batch / (blocks_ms * 1e-3) / 1e12 if blocks_ms > 0 else 0.0
-    achieved = CONV64_FLOP_PER_IMAGE * args.batch / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    conv_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)                  # one conv2 launch
+    blocks_ms = sum(s.elapsed_time(e) for s, e in block_events) / max(len(block_events), 1)     # the 6 whole-block launches of a forward
+    n_block_launch = 6
+    blk_ms = blocks_ms / n_block_launch
+    attn_tf = ATTN_SET_FLOP_PER_IMAGE * args.batch / (blocks_ms * 1e-3) / 1e12 if blocks_ms > 0 else 0.0
+    conv_tf = CONV64_FLOP_PER_IMAGE * args.batch / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    nwin = args.batch * 12 * 20                    # 96x160 token grid -> 12 x 20 windows per 720p image
+    blk_traffic, blk_src = pmc_traffic("fused_block")
+    conv_traffic, conv_src = pmc_traffic("conv64")
+    if args.batch != 8:
+        blk_traffic = conv_traffic = None
+    roof_block = {"bound": "mfma",
+                  "kernel": "fused_qkv_attn_kernel<true,true> (one whole WindowTransformerBlock per launch: norm1 + qkv + window attention + proj + "
+                            "residual + norm2 + fc1 + GELU + fc2 + residual; 6 launches per forward)",
+                  "achieved": attn_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / MFMA_BF16_PEAK_TFLOPS,
+                  "traffic": blk_traffic, "traffic_source": blk_src,
+                  "algorithmic_flop_per_launch": ATTN_SET_FLOP_PER_IMAGE * args.batch / n_block_launch,
+                  "algorithmic_bytes": nwin * 64 * 192 * 4 * 2,       # the fp32 residual stream read once + written once
+                  "ms_per_launch": blk_ms, "total_ms_per_forward": blocks_ms, "launches_timed": len(block_events) * n_block_launch,
+                  "note": "algorithmic FLOPs = SURVEY 8(d)'s window-attention GEMM set (qkv, QK^T, PV, proj, fc1, fc2 = 86.1 GF per image); "
+                          "LayerNorm / softmax / GELU run inside the same launches and are not counted; north_star target frac >= 0.40"}
+    roof_conv = {"bound": "mfma", "kernel": "conv_c64_persistent_kernel<4,0,3> (conv2 64->64 3x3 implicit GEMM; same kernel as decoder_conv1; 2 launches per forward)",
+                 "achieved": conv_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / MFMA_BF16_PEAK_TFLOPS,
+                 "traffic": conv_traffic, "traffic_source": conv_src,
+                 "algorithmic_flop_per_launch": CONV64_FLOP_PER_IMAGE * args.batch,
+                 "algorithmic_bytes": 2 * args.batch * LR_H * LR_W * 64 * 2,
+                 "ms_per_launch": conv_ms, "total_ms_per_forward": 2 * conv_ms, "launches_timed": len(events)}
+    dominant, second = (roof_block, roof_conv) if blocks_ms >= 2 * conv_ms else (roof_conv, roof_block)
 
     if rank == 0:
         out = {
@@ -257,24 +395,24 @@ def main():
                                    f"batch {args.batch} per GPU (BASELINE.json configs[1])",
                        "images_per_gpu_per_step": args.batch, "parallelism": f"replicas x{world}",
                        "weights": "deterministic synthetic (transformerupscaler_amd.weights, seed 0)"},
-            "roofline": {"bound": "mfma", "kernel": "conv_c64_persistent_kernel<4,0,3> (conv2 64->64 3x3 implicit GEMM; same kernel as decoder_conv1)",
-                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic_conv64.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
-                         "algorithmic_bytes": 2 * args.batch * LR_H * LR_W * 64 * 2,
-                         "ms_per_launch": kern_ms, "launches_timed": len(events)},
-            # the north-star's second ask: MFMA utilisation of the window-attention GEMM set (the 6 transformer blocks,
-            # 24 launches per forward, event-timed as one stage; includes their LayerNorm / softmax / GELU work)
-            "attention_gemm_set": {"achieved": attn_set_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": attn_set_tf / MFMA_BF16_PEAK_TFLOPS, "ms_per_forward": blocks_ms,
-                                   "gflop_per_image": ATTN_SET_FLOP_PER_IMAGE / 1e9},
+            "roofline": dominant,
+            "roofline_second": second,
         }
         if train_result is not None:
             out["train"] = train_result
         if rt_result is not None:
             out["rt_train"] = rt_result
+        if x4_result is not None:
+            out["x4"] = x4_result
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.batch)
+            with torch.no_grad():
+                out["cpu_baseline"], out["fidelity"] = cpu_baseline(model, dev)
+            out["psnr_vs_ref_db"] = out["fidelity"]["psnr_vs_ref_db"]
+            if train_result is not None:
+                train_result["cpu_baseline"] = {"value": out["cpu_baseline"]["train_value"], "unit": "images/sec", "cores": out["cpu_baseline"]["cores"],
+                                                "kind": "port", "sample": out["cpu_baseline"]["train_sample"]}
+            if rt_result is not None:
+                rt_result["cpu_baseline"] = rt_cpu_baseline()
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None     # measured on rank 0 at N=1 only (see BENCH at n_gpus=1)
         print(json.dumps(out), flush=True)

@@ -204,15 +204,22 @@ def aa_resize_explicit(x: Tensor, size: Tuple[int, int]) -> Tensor:
 # --------------------------------------------------------------------------------------
 def forward(sd: Dict[str, Tensor], x: Tensor, res_out: Tuple[int, int] = (1080, 1920),
             upscale_factor: Optional[int] = None, require_ratio: bool = True,
-            capture: Optional[dict] = None, clamp: bool = True) -> Tensor:
-    """Eval-mode forward.  ``capture`` (dict) receives named intermediates for per-kernel tests."""
+            capture: Optional[dict] = None, clamp: bool = True, masks: Optional[dict] = None) -> Tensor:
+    """Eval-mode forward.  ``capture`` (dict) receives named intermediates for per-kernel tests.
+
+    ``masks`` (gradient tests only): {"feat1", "feat", "upscaled_input", "dec", "clamp"} -> 0/1 tensors that REPLACE the four
+    ReLU gates and the clamp gate (``relu(z)`` becomes ``z * mask``, ``clamp(z)`` becomes ``z * mask``).  Evaluated at the gates
+    another forward took (the bf16 HIP path), the autograd of this graph is the gradient that path should produce, with the
+    ReLU / clamp decisions factored out -- what remains is kernel arithmetic error."""
+    def gate(z, key):
+        return F.relu(z) if masks is None else z * masks[key].to(z.dtype)
     cap = capture if capture is not None else {}
     res_out, s = resolve_scale(x.shape[2], x.shape[3], res_out, upscale_factor)
 
     # encoder, model.py:251-252 (shared in-place ReLU)
-    feat = F.relu(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], padding=1))
+    feat = gate(F.conv2d(x, sd["conv1.weight"], sd["conv1.bias"], padding=1), "feat1")
     cap["feat1"] = feat
-    feat = F.relu(F.conv2d(feat, sd["conv2.weight"], sd["conv2.bias"], padding=1))
+    feat = gate(F.conv2d(feat, sd["conv2.weight"], sd["conv2.bias"], padding=1), "feat")
     cap["feat"] = feat
     b, c, hf, wf = feat.shape
 
@@ -223,7 +230,7 @@ def forward(sd: Dict[str, Tensor], x: Tensor, res_out: Tuple[int, int] = (1080, 
     # branch A, model.py:264-265 ; BasicConv = conv(no bias)+ReLU, utils.py:32-40
     up = upsampler(sd, "up1", feat, s)
     cap["up1"] = up
-    upscaled_input = F.relu(F.conv2d(up, sd["up1_conv.conv.weight"], None, padding=1))
+    upscaled_input = gate(F.conv2d(up, sd["up1_conv.conv.weight"], None, padding=1), "upscaled_input")
     cap["upscaled_input"] = upscaled_input
 
     # patch embed, model.py:268-270
@@ -265,7 +272,7 @@ def forward(sd: Dict[str, Tensor], x: Tensor, res_out: Tuple[int, int] = (1080, 
     cap["combined"] = combined
 
     # decoder, model.py:312-313
-    dec = F.relu(F.conv2d(combined, sd["decoder_conv1.weight"], sd["decoder_conv1.bias"], padding=1))
+    dec = gate(F.conv2d(combined, sd["decoder_conv1.weight"], sd["decoder_conv1.bias"], padding=1), "dec")
     cap["dec"] = dec
     residual = F.conv2d(dec, sd["decoder_conv2.weight"], sd["decoder_conv2.bias"], padding=1)
     cap["residual"] = residual
@@ -282,6 +289,8 @@ def forward(sd: Dict[str, Tensor], x: Tensor, res_out: Tuple[int, int] = (1080, 
     if require_ratio and tuple(res_out) != (out.shape[2], out.shape[2]):
         out = aa_resize(out, res_out)
     cap["pre_clamp"] = out
+    if masks is not None and clamp:
+        return out * masks["clamp"].to(out.dtype)
     return torch.clamp(out, 0.0, 1.0) if clamp else out  # model.py:327
 
 

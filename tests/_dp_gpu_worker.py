@@ -1,6 +1,7 @@
-"""Worker for tests/test_hip_dp.py: python _dp_gpu_worker.py RANK WORLD PORT OUTFILE.
+"""Worker for tests/test_hip_dp.py: python _dp_gpu_worker.py RANK WORLD INIT_METHOD OUTFILE [rt].
 Both ranks share cuda:0 (one-GPU box), so the collective runs over gloo; the reducer, bucketing and
 backward-overlap logic are the ones the RCCL path uses."""
+import faulthandler
 import importlib
 import os
 import sys
@@ -15,10 +16,10 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    rank, world, port, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = port
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, world, init, outfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    faulthandler.dump_traceback_later(300, exit=True)        # a stall leaves every thread's stack on stderr
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=init, rank=rank, world_size=world)
     if len(sys.argv) > 5 and sys.argv[5] == "rt":
         return main_rt(rank, outfile)
     from transformerupscaler_amd.autograd import resize_aa

@@ -38,6 +38,8 @@ def import_reference():
         def __call__(self, t):
             if tuple(t.shape[-2:]) == self.size:
                 return t
+            if t.dtype in (torch.bfloat16, torch.float16):      # aten's CPU antialias kernel has no half types (calibration run only)
+                return F.interpolate(t.float(), size=self.size, mode="bilinear", align_corners=False, antialias=True).to(t.dtype)
             return F.interpolate(t, size=self.size, mode="bilinear", align_corners=False, antialias=True)
 
     tr.Resize = Resize

@@ -2,7 +2,6 @@
 dictionaries are synthetic; what is under test is the host logic: arrival-order layout, bucketing,
 async all-reduce, averaging, untouched inactive parameters)."""
 import os
-import socket
 
 import pytest
 import torch
@@ -12,19 +11,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
-
-
 def _fake_grads(names, shapes, rank, step):
     from _dp_worker import fake_grads
     return fake_grads(names, shapes, rank, step)
 
 
-def test_reducer_world2_gloo():
-    port = str(_free_port())
+def test_reducer_world2_gloo(tmp_path):
+    """Fixed-scale steps and a mixed-scale step (ranks on different scales) over gloo; file rendezvous (no port to race for)."""
+    init = "file://" + str(tmp_path / "rdzv")
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", init], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
              for r in range(2)]
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
@@ -43,6 +39,27 @@ def test_reducer_single_process_layout():
     red.on_ready(list(reversed(names)), grads)
     out = red.finish()
     assert all(torch.equal(out[n], grads[n]) for n in names)          # world 1: identity
-    late = "up1.upsamplers.2.0.weight"             # not part of scale 4: ignored, never enters the layout
-    red.on_ready([late], {late: torch.zeros(shapes[late])})
-    assert late not in red.finish()
+    assert red.launched_order == list(range(len(red.bucket_ranges)))
+    late = "up1.upsamplers.2.0.weight"             # not part of scale 4: must raise, never be dropped silently
+    with pytest.raises(RuntimeError, match="layout"):
+        red.on_ready([late], {late: torch.zeros(shapes[late])})
+    red._abort()
+    with pytest.raises(RuntimeError, match="layout"):
+        red.begin([late])
+    # a backward that ends without one of its announced gradients is an error, not a silent zero
+    red.begin(names)
+    red.on_ready(names[:-1], grads)
+    with pytest.raises(RuntimeError, match="without gradients"):
+        red.finish()
+
+
+def test_reducer_static_layout_is_backward_order():
+    from transformerupscaler_amd.dp import GradReducer
+    red = GradReducer(2, "cpu", bucket_mb=6.0)
+    order = red.names
+    assert order[0].startswith("final_upscale_conv") and order[-1].startswith("conv1.")
+    assert order.index("window_blocks.5.mlp.2.weight") < order.index("window_blocks.0.mlp.2.weight") < order.index("patch_embed.weight")
+    assert len(red.bucket_ranges) == 3 and all(b > a for a, b in red.bucket_ranges)
+    mixed = GradReducer(None, "cpu", scales=(2, 3, 4, 6))
+    assert mixed.mixed and mixed.flat.numel() > mixed.param_floats          # presence counts ride behind the parameters
+    assert mixed.bucket_ranges[-1][1] == mixed.flat.numel()

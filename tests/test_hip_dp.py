@@ -3,7 +3,6 @@ average of the per-sample gradients = the single-process gradients of the 2-samp
 sum-type loss, rank-averaged grads == (full-batch grads) / world."""
 import importlib
 import os
-import socket
 import subprocess
 import sys
 
@@ -15,23 +14,20 @@ pytestmark = pytest.mark.gpu
 
 
 def run_two_workers(worker, outfile, extra=()):
-    """Two ranks sharing cuda:0 over gloo.  The rendezvous port is picked by binding port 0 and releasing it, which can
-    race with another process on a busy box: one retry on a fresh port if the workers do not finish in time."""
-    last = None
-    for attempt in range(2):
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
-        procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, outfile, *extra], stdout=subprocess.PIPE,
-                                  stderr=subprocess.STDOUT, text=True) for r in range(2)]
-        try:
-            outs = [p.communicate(timeout=150)[0] for p in procs]
-        except subprocess.TimeoutExpired:
-            for p in procs:
-                p.kill()
-            last = [p.communicate()[0] for p in procs]
-            continue
-        assert all(p.returncode == 0 for p in procs), outs
-        return outs
-    pytest.fail(f"DP workers did not finish in two attempts: {last}")
+    """Two ranks sharing cuda:0 over gloo, run ONCE.  Rendezvous through a file in the test's tmp directory (no TCP port to
+    race for); each worker arms faulthandler, so a stall ends with both ranks' Python stacks in the assertion message instead
+    of a silent timeout."""
+    rdzv = outfile + ".rdzv"
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", "file://" + rdzv, outfile, *extra], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=420)[0] for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        pytest.fail("DP workers stalled:\n" + "\n-----\n".join(p.communicate()[0] for p in procs))
+    assert all(p.returncode == 0 for p in procs), outs
+    return outs
 
 
 def test_two_rank_dp_grads_equal_single_process(det_sd, golden_dir, tmp_path):

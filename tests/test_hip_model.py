@@ -1,10 +1,10 @@
 """End-to-end parity of the HIP path (through the nn.Module plugin surface and the C ABI) against
 the oracle and the reference-generated golden fixtures.
 
-Tolerance (bf16 activations, fp32 accumulation; BASELINE.json north_star): PSNR(build, reference
-fp32) >= 50 dB and max |diff| <= 2.5e-2 on [0,1] images; the reference's own CPU bf16-autocast run
-differs from its fp32 run by max 1.9e-3 / 69.7 dB on natural-statistics weights;
-the synthetic weights here have a 3x amplified tail so the bound is looser."""
+Tolerance (bf16 activations, fp32 accumulation; BASELINE.json north_star): max |diff| <= 4e-3 and PSNR(build,
+reference fp32) >= 62 dB on [0,1] images = 4x what the path measures (9.5e-4 / 74 dB; every test prints its own numbers).
+For scale: the reference's own CPU bf16-autocast run differs from its fp32 run by max 6.1e-3..6.7e-3 on these weights
+(tests/golden/calib_bf16_autocast.json) and 1.9e-3 / 69.7 dB on natural-statistics weights."""
 import glob
 import importlib
 import os
@@ -16,7 +16,7 @@ import torch
 from oracle import fast_transformer_oracle as O
 
 pytestmark = pytest.mark.gpu
-MAX_ABS, MIN_PSNR = 2.5e-2, 50.0
+MAX_ABS, MIN_PSNR = 4e-3, 62.0
 
 
 def psnr(a, b):
@@ -48,6 +48,7 @@ def test_forward_matches_reference_fixture(model, golden_dir, name):
     ref = torch.from_numpy(d["y"])
     assert tuple(y.shape) == tuple(ref.shape)
     assert y.min() >= 0 and y.max() <= 1
+    print(f"{name}: max|d| {(y - ref).abs().max().item():.2e} PSNR {psnr(y, ref):.1f} dB")
     assert (y - ref).abs().max().item() <= MAX_ABS, (y - ref).abs().max().item()
     assert psnr(y, ref) >= MIN_PSNR, psnr(y, ref)
 

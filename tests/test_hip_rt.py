@@ -78,7 +78,7 @@ def test_rt_model_matches_reference_fixture(rt_model, golden_dir, name, kw):
         worst = max(worst, diff.abs().max().item()); se += (diff.double() ** 2).sum().item(); n += diff.numel()
     psnr = 10 * np.log10(1.0 / max(se / n, 1e-20))
     print(name, "max abs", worst, "PSNR", psnr)
-    assert worst <= 2.5e-2 and psnr >= 50.0
+    assert worst <= 4e-3 and psnr >= 62.0      # 4x the measured error (tests print theirs)
     assert abs(y.double().mean().item() - d["stats"][0]) < 2e-3
     assert np.abs(y[0].double().mean(dim=(0, 2)).float().numpy() - d["row_means"]).max() < 5e-3
 

@@ -4,11 +4,13 @@ semantics (parameters of unused scales untouched).
 
 Tolerances.  Activations / activation-gradients are bf16 with fp32 accumulation.
  * With a smooth cotangent (loss = sum(out * R), R fixed) every parameter gradient must match the
-   oracle's fp32 autograd to <= 15 % relative L2, median over parameters <= 10 %.  Calibration: the
-   reference graph itself run under torch bf16 autocast on the CPU (same weights / inputs) differs
-   from its fp32 run by 7-13 % (median over parameters) and 15-25 % (worst parameter) relative L2,
-   forward max |diff| 6.5e-3; this path measures 6-8 % median / 8-12 % worst, forward ~1e-3 (the error is dominated by ReLU/clamp
-   mask flips caused by the bf16 forward, which every parameter gradient inherits).
+   oracle's fp32 autograd to the limits of CALIB below.  They are derived from a committed calibration, not from
+   this path's own result: tests/golden/calib_bf16_autocast.json (tests/golden/make_golden_r2.py --only calib) holds how far
+   the REFERENCE graph itself moves when run under torch bf16 autocast on the CPU with the same weights / inputs /
+   cotangent: median over parameters 6.6-7.9 %, worst parameter 9.4-24 % relative L2, forward max |diff| 6.1e-3..6.7e-3.
+   Limit: median <= 1.25 x the largest calibrated median, worst <= min(15 %, largest calibrated worst).  The error is
+   dominated by ReLU / clamp gate flips caused by the bf16 forward, which every parameter gradient inherits;
+   tests/test_hip_parity_r2.py::test_grads_mask_matched_vs_oracle removes the flips and holds the kernels to 2 % / 5 %.
  * With train.py's L1 loss the cotangent is sign(out - hr)/N, which is discontinuous: a forward
    difference of 1e-3 (bf16) flips the sign on the ~0.2 % of pixels with |out - hr| < 1e-3 and that
    alone is a ~4-5 % relative-L2 change of the cotangent.  The fixture comparison therefore allows
@@ -24,6 +26,18 @@ import torch.nn.functional as F
 from oracle import fast_transformer_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+def _calib_limits():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "calib_bf16_autocast.json")) as f:
+        c = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+    med = 1.25 * max(v["grad_rel_l2_median"] for v in c.values())
+    worst = min(0.15, max(v["grad_rel_l2_worst"] for v in c.values()))
+    return med, worst
+
+
+MED_LIMIT, WORST_LIMIT = _calib_limits()
 
 
 def make_model(det_sd):
@@ -84,7 +98,7 @@ def test_grads_fixed_cotangent_vs_oracle(det_sd, scale, shape, kw):
     model = make_model(det_sd).eval()
     y = model(x.cuda(), **kw)
     (y * R.cuda()).sum().backward()
-    assert (y.detach().cpu() - yo.detach()).abs().max() <= 2.5e-2
+    assert (y.detach().cpu() - yo.detach()).abs().max() <= 4e-3
     errs = {}
     for k, p in model.named_parameters():
         ref = leaf[k].grad
@@ -93,11 +107,11 @@ def test_grads_fixed_cotangent_vs_oracle(det_sd, scale, shape, kw):
             continue
         g = p.grad.detach().cpu().double()
         errs[k] = (g - ref.double()).norm().item() / max(ref.double().norm().item(), 1e-12)
-    bad = {k: round(v, 4) for k, v in errs.items() if v > 0.15}
+    bad = {k: round(v, 4) for k, v in errs.items() if v > WORST_LIMIT}
     med = sorted(errs.values())[len(errs) // 2]
     print(f"scale {scale}: relative L2 median {med:.4f} worst {max(errs.values()):.4f} ({max(errs, key=errs.get)})")
     assert not bad, bad
-    assert med <= 0.10, med
+    assert med <= MED_LIMIT, (med, MED_LIMIT)
 
 
 def test_grads_fixed_cotangent_train_geometry(det_sd, golden_dir):
@@ -117,11 +131,11 @@ def test_grads_fixed_cotangent_train_geometry(det_sd, golden_dir):
             continue
         g, ref = p.grad.detach().cpu().double(), leaf[k].grad.double()
         errs[k] = (g - ref).norm().item() / max(ref.norm().item(), 1e-12)
-    bad = {k: round(v, 4) for k, v in errs.items() if v > 0.15}
+    bad = {k: round(v, 4) for k, v in errs.items() if v > WORST_LIMIT}
     med = sorted(errs.values())[len(errs) // 2]
     print(f"train geometry: relative L2 median {med:.4f} worst {max(errs.values()):.4f} ({max(errs, key=errs.get)})")
     assert not bad, bad
-    assert med <= 0.10, med
+    assert med <= MED_LIMIT, (med, MED_LIMIT)
 
 
 def test_adam_step_skips_unused_scales(det_sd, golden_dir):

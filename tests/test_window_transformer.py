@@ -57,8 +57,8 @@ def test_hip_matches_reference_fixture(golden_dir, wt_model, tag, kw):
     err = (y - ref).abs().max().item()
     psnr = 10 * np.log10(1.0 / max(((y - ref) ** 2).mean().item(), 1e-20))
     print(tag, "max abs", err, "PSNR", psnr)
-    assert err <= 2.5e-2 and psnr >= 50.0
-    assert np.abs(y[0, :, :24, :24].numpy() - d["out_f32_patch"]).max() <= 2.5e-2
+    assert err <= 4e-3 and psnr >= 62.0            # 4x the measured error of the sibling plugins (printed above)
+    assert np.abs(y[0, :, :24, :24].numpy() - d["out_f32_patch"]).max() <= 4e-3
 
 
 @pytest.mark.gpu
@@ -73,7 +73,7 @@ def test_hip_1080p_matches_reference_fixture(golden_dir, wt_model):
         worst = max(worst, np.abs(diff).max()); se += (diff ** 2).mean()
     psnr = 10 * np.log10(1.0 / max(se / 16, 1e-20))
     print("1080p max abs", worst, "PSNR", psnr)
-    assert worst <= 2.5e-2 and psnr >= 50.0
+    assert worst <= 4e-3 and psnr >= 62.0
     assert abs(y.double().mean().item() - d["stats"][0]) < 2e-3
     assert np.abs(y[0].double().mean(dim=(0, 2)).float().numpy() - d["row_means"]).max() < 5e-3
 

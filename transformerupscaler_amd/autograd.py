@@ -92,8 +92,9 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, see
     return ops.clamp01(pre), sv
 
 
-def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None) -> Dict[str, torch.Tensor]:
-    """Returns {reference parameter name: gradient} for the parameters active at `scale`."""
+def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_input_grad=False) -> Dict[str, torch.Tensor]:
+    """Returns {reference parameter name: gradient} for the parameters active at `scale` (+ "__input__" = d loss / d x when
+    `want_input_grad`: conv1's input gradient as a 64 -> 3 conv of the flipped weights)."""
     g: Dict[str, torch.Tensor] = {}
 
     def ready(*names):
@@ -195,6 +196,8 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None) -> Dict[
     g_f1 = ops.conv_c64(g_feat, pk["conv2.wd"], None, 1, mask=sv["feat1"])
     g["conv1.weight"], g["conv1.bias"] = ops.conv1_wgrad(x, g_f1)
     ready("conv2.weight", "conv2.bias", "conv1.weight", "conv1.bias")
+    if want_input_grad:
+        g["__input__"] = ops.conv_c64_thin(g_f1, pk["conv1.wd"], None, 3, relu=False)
     return g
 
 
@@ -206,16 +209,25 @@ class _FastTransformerFn(torch.autograd.Function):
         out, sv = forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p, seed)
         ctx.module, ctx.scale, ctx.names, ctx.sv = module, scale, names, sv
         ctx.pk, ctx.frags = pk, (frags_t, frags_n)
+        ctx.x_dtype = x.dtype
         return out
 
     @staticmethod
     def backward(ctx, gout):
         reducer = getattr(ctx.module, "_grad_reducer", None)
+        if reducer is not None:
+            reducer.begin(ctx.names)          # raises if this step's parameters are not in the reducer's layout
         ops.zero_pool_begin(gout.device)
         try:
-            grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout, reducer)
+            grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout, reducer,
+                                   want_input_grad=bool(ctx.needs_input_grad[1]))
+        except BaseException:
+            if reducer is not None:
+                reducer._abort()
+            raise
         finally:
             ops.zero_pool_end()
+        gx = grads.pop("__input__", None)       # the reference supplies d/dx too (an input that requires grad)
         if reducer is not None:
             grads = reducer.finish()          # averaged over ranks (views of the flat bucket buffer)
         ctx.sv = None
@@ -223,7 +235,7 @@ class _FastTransformerFn(torch.autograd.Function):
         for n in ctx.names:
             gr = grads.get(n)
             outs.append(None if gr is None else gr.contiguous().clone() if reducer is not None else gr.contiguous())
-        return (None, None, None, None, None, None) + tuple(outs)
+        return (None, None if gx is None else gx.to(ctx.x_dtype), None, None, None, None) + tuple(outs)
 
 
 def fast_transformer_function(module, x, scale, res_out, require_ratio):

@@ -133,9 +133,15 @@ class _ResidualTransformerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         reducer = getattr(ctx.module, "_grad_reducer", None)
+        if reducer is not None:
+            reducer.begin(ctx.names)          # raises if this step's parameters are not in the reducer's layout
         ops.zero_pool_begin(gout.device)
         try:
             grads = backward_train(ctx.pk, ctx.sv, gout, reducer)
+        except BaseException:
+            if reducer is not None:
+                reducer._abort()
+            raise
         finally:
             ops.zero_pool_end()
         if reducer is not None:

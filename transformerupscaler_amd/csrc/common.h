@@ -143,4 +143,14 @@ TUP_DEVICE float drop_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float 
     return drop_hash(seed, idx) >= thresh ? inv_keep : 0.f;
 }
 
+// Raises a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; a process-wide flag would leave
+// every device after the first at the 64 KB default).
+#define TUP_SET_DYN_LDS(fn, bytes) do { \
+        static unsigned long long done_ = 0; int dev_ = 0; \
+        hipError_t e_ = hipGetDevice(&dev_); if (e_ != hipSuccess) return (int)e_; \
+        if (!((done_ >> (dev_ & 63)) & 1ull)) { \
+            e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e_ != hipSuccess) return (int)e_; \
+            done_ |= 1ull << (dev_ & 63); } } while (0)
+
 #define TUP_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

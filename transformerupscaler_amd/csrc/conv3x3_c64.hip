@@ -551,13 +551,7 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     constexpr int NPIX_HALO = (TH + KS - 1) * (TW + KS - 1);
     constexpr size_t lds = (size_t)KS * KS * CT * 16 * 128 + 2 * (size_t)NPIX_HALO * 128 + 256;     // + bias
     static_assert(lds <= 163840, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_c64_persistent_kernel<CT, OUT_MODE, KS>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((conv_c64_persistent_kernel<CT, OUT_MODE, KS>), lds);
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -705,15 +699,13 @@ extern "C" int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const f
         conv3x3_c64_kernel<1, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), in_tile_bytes(5) + 2 * 16 * 128, s>>>(
             (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, r, nout, relu, tilesX, tilesY, 1);
     } else if (r == 3) {
-        static bool set3 = false;
         const size_t lds = in_tile_bytes(5) + 2 * 32 * 128;
-        if (!set3) { hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<2, OUT_PLANAR_F32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set3 = true; }
+        TUP_SET_DYN_LDS((conv3x3_c64_kernel<2, OUT_PLANAR_F32, 5>), lds);
         conv3x3_c64_kernel<2, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
             (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, r, nout, relu, tilesX, tilesY, 1);
     } else {
-        static bool set6 = false;
         const size_t lds = in_tile_bytes(5) + 2 * 112 * 128;
-        if (!set6) { hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_kernel<7, OUT_PLANAR_F32, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; set6 = true; }
+        TUP_SET_DYN_LDS((conv3x3_c64_kernel<7, OUT_PLANAR_F32, 5>), lds);
         conv3x3_c64_kernel<7, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), lds, s>>>(
             (const bf16_t*)x, (const bf16_t*)wp, bias, nullptr, nullptr, out, H, W, 1, r, nout, relu, tilesX, tilesY, 1);
     }

@@ -570,13 +570,8 @@ static int conv_c64_wgrad_launch(const void* x, const void* gmap, float* dwp, fl
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
     const size_t lds = X_TILE_BYTES + 256 * 128;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wgrad_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((conv3x3_wgrad_c64_kernel), lds);
     conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, 1)), dim3(512), lds, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)x, (const bf16_t*)gmap, dwp, dbias, B, H, W, gr, sp, tilesX, tilesY, xr, xsp);
     TUP_CHECK_LAUNCH();

@@ -546,12 +546,7 @@ extern "C" int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const 
                                       const float* bias_frag, void* out, int nwin, void* stream)
 {
     if (nwin <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((fused_qkv_attn_kernel<false>), FA_LDS);
     fused_qkv_attn_kernel<false><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
         x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, (bf16_t*)out, nwin, nullptr, nullptr, nullptr, MlpArgs{});
     TUP_CHECK_LAUNCH();
@@ -564,12 +559,7 @@ extern "C" int tup_fused_attn_block_fwd(float* x, const float* gamma, const floa
                                         const float* bias_frag, const void* wproj, const float* bproj, int nwin, void* stream)
 {
     if (nwin <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true>), FA_LDS);
     fused_qkv_attn_kernel<true><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
         x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, MlpArgs{});
     TUP_CHECK_LAUNCH();
@@ -584,12 +574,7 @@ extern "C" int tup_fused_block_fwd(float* x, const float* gamma1, const float* b
                                    const void* w2, const float* b2, int nwin, void* stream)
 {
     if (nwin <= 0) return 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fused_qkv_attn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
     const MlpArgs ma{gamma2, beta2, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
     fused_qkv_attn_kernel<true, true><<<dim3((nwin + 1) / 2), dim3(256), FB_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
         x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, ma);

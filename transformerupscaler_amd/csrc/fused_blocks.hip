@@ -286,12 +286,7 @@ extern "C" int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta
     if (M <= 0) return 0;
     {
         constexpr size_t lds2 = V2_LDS;
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)fused_mlp_v2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            if (e != hipSuccess) return (int)e;
-            attr2_set = true;
-        }
+        TUP_SET_DYN_LDS((fused_mlp_v2_kernel<0>), lds2);
         const dim3 grid((M + BM2 - 1) / BM2);
         hipStream_t st = reinterpret_cast<hipStream_t>(stream);
         const char* abl = getenv("TUP_MLP_ABLATE");            // timing experiments only (results are wrong)

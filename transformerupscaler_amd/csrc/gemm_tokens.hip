@@ -729,12 +729,7 @@ int launch_panel(const GemmParams& p, hipStream_t s)
         return 0;
     }
     constexpr size_t lds = PA_BYTES + PW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_panel_kernel<AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((gemm_panel_kernel<AMODE, EPI>), lds);
     gemm_panel_kernel<AMODE, EPI><<<dim3((p.M + PBM - 1) / PBM), dim3(256), lds, s>>>(p);
     TUP_CHECK_LAUNCH();
     return 0;
@@ -901,12 +896,7 @@ int launch_patch_embed(const GemmParams& p, hipStream_t s)
 {
     if (p.M <= 0) return 0;
     constexpr size_t lds = 2 * (size_t)(PE_A_BYTES + NT64 * 64 * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)patch_embed_kernel<NT64, AMODE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    TUP_SET_DYN_LDS((patch_embed_kernel<NT64, AMODE, EPI>), lds);
     patch_embed_kernel<NT64, AMODE, EPI><<<dim3((p.M + PE_BM - 1) / PE_BM), dim3(512), lds, s>>>(p);
     TUP_CHECK_LAUNCH();
     return 0;

@@ -3,69 +3,187 @@ xGMI, launched from inside the backward so the reduction overlaps the remaining 
 
 The reference has no distributed code at all; this is the DP layer required by
 BASELINE.json.  Design for MI355X: the whole active gradient set is 4.49 M floats (17.9 MB fp32), so it
-lives in ONE flat fp32 buffer cut into a few multi-MB buckets in backward-completion order (tail convs
--> blocks 5..0 -> patch_embed -> up-branch -> conv2/conv1); each bucket is one ring/tree all-reduce
-on a dedicated HIP stream (xGMI is point-to-point, so few large messages beat many small ones).
-Only parameters active at the training scale are reduced; the other scales' upsamplers keep
-``grad is None`` and Adam skips them exactly as in the reference.  All ranks must train the
-same scale in a step.
+lives in ONE flat fp32 buffer with a STATIC layout in backward-completion order (tail convs -> blocks 5..0
+-> patch_embed -> up-branch -> conv2/conv1) cut into a few multi-MB buckets; each bucket is one all-reduce
+on a dedicated HIP stream (xGMI is point-to-point, so few large messages beat many small ones).  Buckets
+are always issued in index order, so every rank issues the same sequence of collectives whatever order its
+gradients arrive in.
+
+Two layouts:
+ * ``scale=s``  -- every rank trains scale ``s`` in every step (the benchmark configuration).  Only the
+   parameters active at that scale are in the buffer; the other scales' upsamplers keep ``grad is None``
+   and Adam skips them exactly as in the reference.  A gradient outside the layout raises.
+ * ``scales=(2, 3, 4, 6)`` -- ranks / steps may train different scales (the reference dataset mixes
+   scales inside one step, data_handling/data_class.py:34-45, train.py:119-133; SURVEY §8(e) "wrinkle").
+   The buffer spans the union; a rank contributes zeros for what it did not produce ("missing grads are
+   zeros for the reduce only") and a per-parameter presence count rides in the last bucket, so a parameter
+   gets a gradient iff at least one rank produced one (otherwise ``None`` -> Adam skips it on all ranks).
+
+One backward node = one begin() / on_ready()... / finish() episode; with train.py's per-sample loop
+(several forwards, one ``loss.backward()``) every sample's node runs its own episode, so all ranks must
+run the same number of forward calls per step.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
-from . import autograd as _ag
-from .weights import active_param_names, param_shapes
+from .weights import VALID_SCALES, active_param_names, param_shapes
+
+
+def _ft_backward_key(name: str):
+    """Sort key = the order in which autograd.backward_train finalises FastTransformer gradients."""
+    if name.startswith("final_upscale_conv."):
+        return (0, 0)
+    if name.startswith("final_upscale.upsamplers."):
+        return (1, -int(name.split(".")[3]))
+    if name.startswith("decoder_conv2."):
+        return (2, 0)
+    if name.startswith("decoder_conv1."):
+        return (3, 0)
+    if name.startswith("patch_unembed."):
+        return (4, 0)
+    if name.startswith("window_blocks."):
+        return (5, -int(name.split(".")[1]))
+    if name.startswith("patch_embed."):
+        return (6, 0)
+    if name.startswith("up1_conv."):
+        return (7, 0)
+    if name.startswith("up1.upsamplers."):
+        return (8, -int(name.split(".")[3]))
+    if name.startswith("conv2."):
+        return (9, 0)
+    if name.startswith("conv1."):
+        return (10, 0)
+    return (11, 0)
 
 
 class GradReducer:
     def __init__(self, scale: Optional[int], device, process_group=None, bucket_mb: float = 6.0, names: Optional[List[str]] = None,
-                 shapes: Optional[Dict[str, tuple]] = None):
-        """scale: FastTransformer training scale (selects the active parameter set); pass scale=None with explicit
-        `names` + `shapes` for a model whose parameters are all active (ResidualTransformer)."""
+                 shapes: Optional[Dict[str, tuple]] = None, scales: Optional[Sequence[int]] = None):
+        """scale: fixed FastTransformer training scale; scales: several scales (mixed-scale layout); or pass scale=None with
+        explicit `names` (+ `shapes`) in expected backward order for a model whose parameters are all active
+        (ResidualTransformer, WindowTransformer)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         shapes = dict(shapes) if shapes is not None else param_shapes()
-        self.names = list(names) if names is not None else active_param_names(scale)
-        self.shapes = {n: shapes[n] for n in self.names}
-        self.numel = {n: int(torch.Size(self.shapes[n]).numel()) for n in self.names}
+        if names is not None:
+            layout = list(names)
+            self.mixed = False
+        elif scales is not None:
+            scales = tuple(int(s) for s in scales)
+            if not scales or any(s not in VALID_SCALES for s in scales):
+                raise ValueError(f"scales must be a non-empty subset of {VALID_SCALES}")
+            seen = set()
+            layout = [n for s in scales for n in active_param_names(s) if not (n in seen or seen.add(n))]
+            layout.sort(key=_ft_backward_key)
+            self.mixed = len(scales) > 1
+        else:
+            layout = sorted(active_param_names(scale), key=_ft_backward_key)
+            self.mixed = False
+        self.names: List[str] = layout
+        self.shapes = {n: tuple(shapes[n]) for n in layout}
+        self.numel = {n: int(torch.Size(self.shapes[n]).numel()) for n in layout}
         self.device = torch.device(device)
-        self.flat = torch.zeros(sum(self.numel.values()), dtype=torch.float32, device=self.device)
-        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
-        self.offset: Dict[str, int] = {}        # assigned lazily in arrival order (= backward order)
-        self._cursor = 0
-        self._bucket_start = 0
-        self._works = []
-        self._layout_frozen = False
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # static layout, 64-float (256 B) aligned segments
+        self.offset: Dict[str, int] = {}
+        cur = 0
+        for n in layout:
+            self.offset[n] = cur
+            cur += (self.numel[n] + 63) // 64 * 64
+        self.param_floats = cur
+        self.index = {n: i for i, n in enumerate(layout)}
+        self.presence_off = cur                              # mixed layout: one float per parameter, reduced with the last bucket
+        total = cur + ((len(layout) + 63) // 64 * 64 if self.mixed else 0)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # buckets of >= bucket_mb in layout order
+        bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
         self.bucket_ranges: List[tuple] = []
+        self.bucket_of: Dict[str, int] = {}
+        a = 0
+        for n in layout:
+            self.bucket_of[n] = len(self.bucket_ranges)
+            end = self.offset[n] + (self.numel[n] + 63) // 64 * 64
+            if end - a >= bucket_elems:
+                self.bucket_ranges.append((a, end))
+                a = end
+        if a < cur or not self.bucket_ranges:
+            self.bucket_ranges.append((a, cur))
+        for n in layout:                                     # a trailing short bucket was merged into a new last one above
+            self.bucket_of[n] = min(self.bucket_of[n], len(self.bucket_ranges) - 1)
+        if total > cur:                                      # presence counts ride in the last bucket
+            self.bucket_ranges[-1] = (self.bucket_ranges[-1][0], total)
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._works: list = []
+        self._in_step = False
+        self._active: Optional[frozenset] = None
+        self._arrived: set = set()
+        self._pending: List[int] = []
+        self._next_bucket = 0
+        self._presence_cache: Dict[frozenset, torch.Tensor] = {}
+        self.launched_order: List[int] = []                  # bucket indices in issue order of the last episode (tests)
 
-    # ---- called from the backward (autograd.grad_ready_hook) ----
+    # ---- episode start: called by the autograd node before its first gradient ----
+    def begin(self, active: Optional[Iterable[str]] = None) -> None:
+        if self._in_step:
+            raise RuntimeError("GradReducer.begin() called while a backward episode is still open (finish() missing)")
+        if active is None:
+            if self.mixed:
+                raise RuntimeError("a mixed-scale GradReducer needs begin(active_names) before the first gradient")
+            act = frozenset(self.names)
+        else:
+            act = frozenset(active)
+            stray = [n for n in act if n not in self.offset]
+            if stray:
+                raise RuntimeError(f"gradients for {stray[:3]}{'...' if len(stray) > 3 else ''} are not in this reducer's layout: "
+                                   "the step's scale differs from DataParallel(scale=...); build it with scales=(...) for mixed-scale steps")
+        self._in_step, self._active, self._arrived = True, act, set()
+        self._pending = [0] * len(self.bucket_ranges)
+        for n in act:
+            self._pending[self.bucket_of[n]] += 1
+        self._next_bucket = 0
+        self.launched_order = []
+        if len(act) != len(self.names):                      # segments this rank will not fill count as zeros in the sum
+            self.flat.zero_()
+        if self.mixed:
+            pres = self._presence_cache.get(act)
+            if pres is None:
+                pres = torch.zeros(self.flat.numel() - self.presence_off, dtype=torch.float32)
+                pres[[self.index[n] for n in act]] = 1.0
+                pres = self._presence_cache[act] = pres.to(self.device)
+            self.flat[self.presence_off:].copy_(pres)
+        self._advance()
+
+    # ---- called from the backward as soon as a group of gradients is final ----
     def on_ready(self, names: List[str], grads: Dict[str, torch.Tensor]) -> None:
+        if not self._in_step:
+            self.begin(None)
         for n in names:
-            if n not in self.numel:
-                continue
             if n not in self.offset:
-                if self._layout_frozen:
-                    raise RuntimeError(f"gradient {n} arrived that was not part of the first step's layout")
-                self.offset[n] = self._cursor
-                self._cursor += self.numel[n]
+                raise RuntimeError(f"gradient {n} is not in this reducer's layout (scale mismatch with DataParallel(scale=...))")
+            if n not in self._active:
+                raise RuntimeError(f"gradient {n} was not announced in begin() for this backward")
+            if n in self._arrived:
+                raise RuntimeError(f"gradient {n} arrived twice in one backward")
             o = self.offset[n]
             self.flat[o:o + self.numel[n]].copy_(grads[n].reshape(-1))
-            self._filled = max(getattr(self, "_filled", 0), o + self.numel[n])
-        if self._filled - self._bucket_start >= self.bucket_elems:
-            self._launch(self._bucket_start, self._filled)
-            self._bucket_start = self._filled
+            self._arrived.add(n)
+            self._pending[self.bucket_of[n]] -= 1
+        self._advance()
 
-    def _launch(self, a: int, b: int) -> None:
-        if b <= a:
-            return
-        if not self._layout_frozen:
-            self.bucket_ranges.append((a, b))
-        if self.world == 1:
+    def _advance(self) -> None:
+        """Issue every bucket whose predecessors are issued and whose own gradients are all in (index order only)."""
+        nb = len(self.bucket_ranges)
+        while self._next_bucket < nb and self._pending[self._next_bucket] == 0:
+            self._launch(self._next_bucket)
+            self._next_bucket += 1
+
+    def _launch(self, k: int) -> None:
+        a, b = self.bucket_ranges[k]
+        self.launched_order.append(k)
+        if self.world == 1 or b <= a:
             return
         view = self.flat[a:b]
         if self.comm_stream is not None:
@@ -79,41 +197,68 @@ class GradReducer:
 
     # ---- called at the end of the backward ----
     def finish(self) -> Dict[str, torch.Tensor]:
-        """Flush the last bucket, wait for every all-reduce, average, and hand back per-parameter views."""
-        self._launch(self._bucket_start, getattr(self, "_filled", 0))
+        """Wait for every all-reduce, average, and hand back per-parameter views of the flat buffer."""
+        if not self._in_step:
+            self.begin(None)
+        missing = self._active - self._arrived
+        if missing:
+            self._abort()
+            raise RuntimeError(f"backward finished without gradients for {sorted(missing)[:3]} (announced in begin())")
+        self._advance()
+        assert self._next_bucket == len(self.bucket_ranges)
         for w in self._works:
             w.wait()
         if self.comm_stream is not None and self.world > 1:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         self._works = []
         if self.world > 1:
-            self.flat[:self._cursor].mul_(1.0 / self.world)
-        out = {n: self.flat[o:o + self.numel[n]].view(self.shapes[n]) for n, o in self.offset.items()}
-        self._layout_frozen = True
-        self._bucket_start = 0
-        self._filled = 0
+            self.flat.mul_(1.0 / self.world)
+        if self.mixed:
+            pres = self.flat[self.presence_off:self.presence_off + len(self.names)].cpu()
+            have = [n for n in self.names if pres[self.index[n]].item() > 0.0]
+        else:
+            have = [n for n in self.names if n in self._active]
+        out = {n: self.flat[self.offset[n]:self.offset[n] + self.numel[n]].view(self.shapes[n]) for n in have}
+        self._in_step, self._active = False, None
         return out
+
+    def _abort(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._in_step, self._active = False, None
 
 
 class DataParallel:
     """Attach a GradReducer to the model's backward.  Usage (mirrors train.py's loop, one process per GPU):
 
-        dp = DataParallel(model, scale=2)            # after dist.init_process_group("nccl")
+        torch.cuda.set_device(local_rank); dist.init_process_group("nccl")       # "nccl" is RCCL on ROCm
+        model = TransformerModel().to(f"cuda:{local_rank}")
+        dp = DataParallel(model, scale=2)            # or scales=(2, 3, 4, 6) for mixed-scale steps
         loss = criterion(resize(model(lr, ...)), hr); loss.backward(); optimizer.step()
 
-    Parameters are broadcast from rank 0 at construction so every replica starts identical."""
+    Parameters are broadcast from rank 0 at construction so every replica starts identical (and the module's
+    packed-weight cache is dropped, since the broadcast writes the parameters in place)."""
 
-    def __init__(self, module, scale: Optional[int] = None, process_group=None, bucket_mb: float = 6.0):
+    def __init__(self, module, scale: Optional[int] = None, process_group=None, bucket_mb: float = 6.0,
+                 scales: Optional[Sequence[int]] = None):
         self.module = module
         dev = next(module.parameters()).device
-        if scale is None:        # every parameter is active (ResidualTransformer): take names / shapes from the module
-            named = {n: tuple(p.shape) for n, p in module.named_parameters() if p.requires_grad}
-            self.reducer = GradReducer(None, dev, process_group, bucket_mb, names=list(named), shapes=named)
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            raise RuntimeError(f"the module lives on {dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                               "call torch.cuda.set_device(local_rank) before building the model (kernels launch on the current device)")
+        if scale is None and scales is None:   # every parameter is active (ResidualTransformer): names / shapes from the module
+            named = [(n, tuple(p.shape)) for n, p in module.named_parameters() if p.requires_grad]
+            named.reverse()                    # backward finalises parameters roughly in reverse definition order
+            self.reducer = GradReducer(None, dev, process_group, bucket_mb, names=[n for n, _ in named], shapes=dict(named))
         else:
-            self.reducer = GradReducer(scale, dev, process_group, bucket_mb)
+            self.reducer = GradReducer(scale, dev, process_group, bucket_mb, scales=scales)
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
-            for p in module.parameters():
-                dist.broadcast(p.data, src=0, group=process_group)
+            with torch.no_grad():
+                for p in module.parameters():
+                    dist.broadcast(p.data, src=0, group=process_group)
+        if hasattr(module, "invalidate_packed"):
+            module.invalidate_packed()
         module._grad_reducer = self.reducer
 
     def detach(self):

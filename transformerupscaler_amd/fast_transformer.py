@@ -148,6 +148,13 @@ class TransformerModel(nn.Module):
     def _versions(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def invalidate_packed(self) -> None:
+        """Drop the packed-weight cache.  Needed after writes that bypass autograd's version counter
+        (``p.data.copy_(...)`` -- the EMA / weight-swap idiom -- or ``dist.broadcast(p.data)``): the cache key is
+        (data_ptr, p._version) per parameter and such writes change neither.  Optimizer steps, ``load_state_dict`` and
+        ``.to()`` are detected automatically."""
+        self._pack_cache = {}
+
     def packed(self, scale: int, backward: bool = False):
         """Packed weights (+ dense relative-position biases) for `scale`; re-packed when any parameter
         was updated in place (optimizer step) or moved."""

@@ -24,6 +24,10 @@ def _stream():
 def _chk(t: torch.Tensor, dtype, shape=None, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError(f"{name}: the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # every launch goes to the CURRENT device's stream: a tensor of another device would be a wild pointer there
+        raise RuntimeError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(...) (one process per GPU) before building / calling the model")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():

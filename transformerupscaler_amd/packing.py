@@ -263,6 +263,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         return pk
     # ---- extra packings the backward needs ----
     t = lambda k: sd[k].detach()
+    pk["conv1.wd"] = pack_conv_c64_thin(t("conv1.weight").flip(2, 3).transpose(0, 1).contiguous())    # d/dx: a 64 -> 3 conv
     pk["conv2.wd"] = pack_conv_c64_dgrad(t("conv2.weight"), 1)
     pk["dec1.wd"] = pack_conv_c64_dgrad(t("decoder_conv1.weight"), 1)
     pk["dec2.wd"] = pack_conv_thin_dgrad(t("decoder_conv2.weight"))

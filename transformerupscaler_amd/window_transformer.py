@@ -49,6 +49,10 @@ class TransformerModel(nn.Module):
         base = (torch.initial_seed() + 7919 * int(os.environ.get("RANK", "0"))) & 0x7FFFFFFF
         return self.dropout_p, (base * 2654435761 + self._dropout_calls) & 0xFFFFFFFF
 
+    def invalidate_packed(self) -> None:
+        """Drop the packed-weight cache (after ``p.data`` writes, which do not bump the version counter the cache is keyed on)."""
+        self._pack_cache = {}
+
     def packed(self, backward: bool = False):
         """(packed weights, T-layout bias fragments[, N-layout fragments for the backward])."""
         ver = tuple((p.data_ptr(), p._version) for p in self.parameters())

@@ -405,8 +405,7 @@ def main():
         if x4_result is not None:
             out["x4"] = x4_result
         if not args.no_cpu_baseline and world == 1:
-            with torch.no_grad():
-                out["cpu_baseline"], out["fidelity"] = cpu_baseline(model, dev)
+            out["cpu_baseline"], out["fidelity"] = cpu_baseline(model, dev)
             out["psnr_vs_ref_db"] = out["fidelity"]["psnr_vs_ref_db"]
             if train_result is not None:
                 train_result["cpu_baseline"] = {"value": out["cpu_baseline"]["train_value"], "unit": "images/sec", "cores": out["cpu_baseline"]["cores"],

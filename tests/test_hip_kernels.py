@@ -526,7 +526,63 @@ def test_fused_block_equals_two_halves(dev, nwin):
     w1f, w2p = packing.pack_fc1_fused(w1).to(dev), packing.pack_linear(w2).to(dev)
     two = ops.fused_attn_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp)
     two = ops.fused_mlp(two, gm2, bt2, w1f, b1, w2p, b2)
-    one = ops.fused_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp, gm2, bt2, w1f, b1, w2p, b2)
+    one = ops.fused_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp, gm2, bt2, w1f, b1, w2p, b2, tokens_per_wave=32)
     assert torch.isfinite(one).all()
     assert (one - two).abs().max().item() <= 1e-5, (one - two).abs().max().item()
     assert (one - x).abs().max().item() > 0.1            # the block did something
+
+
+def _block_operands(dev, nwin, seed=23):
+    from transformerupscaler_amd import ops, packing
+    g = torch.Generator().manual_seed(seed)
+    M = nwin * 64
+    raw = dict(x=torch.randn((M, 192), generator=g),
+               gm1=1 + 0.1 * torch.randn(192, generator=g), bt1=0.1 * torch.randn(192, generator=g),
+               gm2=1 + 0.1 * torch.randn(192, generator=g), bt2=0.1 * torch.randn(192, generator=g),
+               w=torch.randn((576, 192), generator=g) / 192 ** 0.5, b=0.1 * torch.randn(576, generator=g),
+               wp=torch.randn((192, 192), generator=g) / 192 ** 0.5, bp=0.1 * torch.randn(192, generator=g),
+               w1=torch.randn((768, 192), generator=g) * 0.08, b1=0.2 * torch.randn(768, generator=g),
+               w2=torch.randn((192, 768), generator=g) * 0.05, b2=0.2 * torch.randn(192, generator=g),
+               table=0.5 * torch.randn((225, 12), generator=g))
+    wh, bh = packing.pack_qkv_heads(raw["w"], raw["b"])
+    args = [raw["gm1"].to(dev), raw["bt1"].to(dev), wh.to(dev), bh.to(dev), ops.relpos_bias_expand(raw["table"].to(dev)),
+            packing.pack_proj_pairs(raw["wp"]).to(dev), raw["bp"].to(dev), raw["gm2"].to(dev), raw["bt2"].to(dev),
+            packing.pack_fc1_fused(raw["w1"]).to(dev), raw["b1"].to(dev), packing.pack_linear(raw["w2"]).to(dev), raw["b2"].to(dev)]
+    return raw, args
+
+
+def _block_torch(raw, nwin):
+    """WindowTransformerBlock.forward (model.py:153-172) in torch fp32 on bf16-rounded GEMM operands."""
+    x = raw["x"]
+    M = nwin * 64
+    y = bf(F.layer_norm(x, (192,), raw["gm1"], raw["bt1"], 1e-5))
+    qkv = (y @ bf(raw["w"]).t() + raw["b"]).view(nwin, 64, 3, 12, 16).permute(2, 0, 3, 1, 4)
+    ys, xs = torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij")
+    ys, xs = ys.flatten(), xs.flatten()
+    idx = (ys[:, None] - ys[None, :] + 7) * 15 + (xs[:, None] - xs[None, :] + 7)
+    bias = raw["table"][idx.view(-1)].view(64, 64, 12).permute(2, 0, 1)
+    attn = torch.softmax(bf(qkv[0] * 0.25) @ bf(qkv[1]).transpose(-2, -1) + bias, dim=-1)
+    att = bf((bf(attn) @ bf(qkv[2])).transpose(1, 2).reshape(M, 192))
+    x1 = x + att @ bf(raw["wp"]).t() + raw["bp"]
+    y2 = bf(F.layer_norm(x1, (192,), raw["gm2"], raw["bt2"], 1e-5))
+    return x1 + F.linear(bf(F.gelu(F.linear(y2, bf(raw["w1"]), raw["b1"]))), bf(raw["w2"]), raw["b2"])
+
+
+@pytest.mark.parametrize("nwin", [1, 3, 4, 5, 64, 1920])
+def test_block64_vs_torch_and_block32(dev, nwin):
+    """tup_fused_block64_fwd (one wave per window, K / V in registers) against torch fp32 on bf16-rounded operands, and
+    against the two-waves-per-window kernel it replaces.  1920 windows = what one launch of BASELINE configs[1] processes
+    (8 x 240); 1, 3, 5 exercise the inactive-wave paths of the 4-window workgroup."""
+    from transformerupscaler_amd import ops
+    raw, args = _block_operands(dev, nwin)
+    x = raw["x"].to(dev)
+    b64 = ops.fused_block(x.clone(), *args, tokens_per_wave=64)
+    b32 = ops.fused_block(x.clone(), *args, tokens_per_wave=32)
+    assert torch.isfinite(b64).all()
+    d = (b64 - b32).abs().max().item()
+    ref = _block_torch(raw, nwin)
+    e64, e32 = (b64.cpu() - ref).abs().max().item(), (b32.cpu() - ref).abs().max().item()
+    print(f"nwin {nwin}: |b64 - b32| {d:.3e}; vs torch: b64 {e64:.3e}, b32 {e32:.3e} (|ref| max {ref.abs().max().item():.2f})")
+    assert e64 <= 3e-2 + 1e-2 * ref.abs().max().item(), e64
+    assert d <= 2e-2, d                                  # same arithmetic; the softmax normalisation is applied to O instead of P
+    assert (b64 - x).abs().max().item() > 0.1            # the block did something

@@ -266,11 +266,16 @@ def fused_attn_block(x, gamma, beta, wh, bh, bias_frag, wproj, bproj):
     return x
 
 
-def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2):
+# which whole-block kernel runs: 64 = one wave per window (fused_block64.hip), 32 = two waves per window (fused_attn.hip)
+block_tokens_per_wave = int(os.environ.get("TUP_BLOCK_TOKENS_PER_WAVE", "64"))
+
+
+def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2, tokens_per_wave=None):
     """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion)."""
     M = x.shape[0]
     assert M % 64 == 0
-    _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
+    tpw = block_tokens_per_wave if tokens_per_wave is None else tokens_per_wave
+    _lib.call("tup_fused_block64_fwd" if tpw == 64 else "tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
               _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
               _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"),
               _chk(gamma2, F32, (192,), "gamma2"), _chk(beta2, F32, (192,), "beta2"),

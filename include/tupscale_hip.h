@@ -330,15 +330,16 @@ int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const
                         const float* gamma2, const float* beta2, const void* w1, const float* b1,
                         const void* w2, const float* b2, int nwin, void* stream);
 
-/* The same block with ONE WAVE PER WINDOW (64 tokens = four MFMA token tiles per wave, one 256-thread workgroup per CU with the
- * whole register file): K and V never leave the registers (V comes out of the qkv product transposed by swapping its
- * operands), every LDS weight fragment feeds 4 MFMAs, the weight stream is shared by 256 tokens.  Same arguments, packing and
- * results (bit for bit) as tup_fused_block_fwd; replaces WindowTransformerBlock.forward, model.py:153-172 with
- * WindowAttention.forward :104-133 inside. */
-int tup_fused_block64_fwd(float* x, const float* gamma1, const float* beta1, const void* wh, const float* bh,
-                          const float* bias_frag, const void* wproj, const float* bproj,
-                          const float* gamma2, const float* beta2, const void* w1, const float* b1,
-                          const void* w2, const float* b2, int nwin, void* stream);
+/* nblk consecutive WindowTransformerBlocks in ONE launch with ONE WAVE PER WINDOW (64 tokens = four MFMA token tiles per wave,
+ * one 256-thread workgroup per CU with the whole register file): replaces the loop `for block in self.window_blocks`,
+ * model.py:288-289, with WindowTransformerBlock.forward :153-172 and WindowAttention.forward :104-133 inside.  K and V never
+ * leave the registers (V comes out of the qkv product transposed by swapping its operands), every LDS weight fragment feeds 4
+ * MFMAs, the weight stream is shared by 256 tokens; a window never meets another window, so its wave carries it through all
+ * nblk blocks and HBM sees x once in and once out.
+ * x fp32 [64*nwin][192] in window order, updated in place.  table: HOST array [nblk][13] (nblk <= 8) of device pointers,
+ * per block the arguments of tup_fused_block_fwd after x, in that order and packing
+ * (gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2); it is copied into the kernel arguments. */
+int tup_fused_blocks64_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
 
 #ifdef __cplusplus
 }

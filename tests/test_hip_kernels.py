@@ -586,3 +586,19 @@ def test_block64_vs_torch_and_block32(dev, nwin):
     assert e64 <= 3e-2 + 1e-2 * ref.abs().max().item(), e64
     assert d <= 2e-2, d                                  # same arithmetic; the softmax normalisation is applied to O instead of P
     assert (b64 - x).abs().max().item() > 0.1            # the block did something
+
+
+def test_blocks64_six_in_one_launch_equals_six_launches(dev):
+    """tup_fused_blocks64_fwd with nblk = 6 (the model's loop, model.py:288-289, in one launch; x passes between blocks as the
+    wave's own store + load) against six single-block launches: same kernel body, identical results."""
+    from transformerupscaler_amd import ops
+    nwin = 37
+    ops_ = [_block_operands(dev, nwin, seed=40 + i)[1] for i in range(3)]
+    x = _block_operands(dev, nwin, seed=50)[0]["x"].to(dev)
+    seq = [ops_[i % 3] for i in range(6)]
+    one = ops.fused_blocks64(x.clone(), ops.block_table([tuple(a) for a in seq]))
+    ref = x.clone()
+    for a in seq:
+        ops.fused_block(ref, *a, tokens_per_wave=64)
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, ref)

@@ -69,6 +69,29 @@ TUP_DEVICE f32x4 mfma16x16x16(s16x4 a, s16x4 b, f32x4 c) {
 // lane group touches land on 16 distinct 16-byte slots of the 256-byte bank row.
 TUP_DEVICE int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// max / sum over the four lane groups g (lanes l, l^16, l^32, l^48) without LDS: v_permlane16_swap / v_permlane32_swap
+// (hipcc folds an arithmetic combination of the swap's two results to its first operand when both inputs are the same value --
+// it drops the cross-lane exchange -- so the second result passes through an empty asm; v_max in asm also avoids the
+// canonicalising v_max x, x pair hipcc puts in front of fmaxf)
+TUP_DEVICE uint32_t opaque_copy(uint32_t u) { asm volatile("" : "+v"(u)); return u; }
+TUP_DEVICE float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+TUP_DEVICE float rows_max(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = vmax(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, opaque_copy(r[1])));
+    const uint32_t w = __builtin_bit_cast(uint32_t, m);
+    const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return vmax(__builtin_bit_cast(float, q[0]), __builtin_bit_cast(float, opaque_copy(q[1])));
+}
+TUP_DEVICE float rows_sum(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, opaque_copy(r[1]));
+    const uint32_t w = __builtin_bit_cast(uint32_t, m);
+    const auto q = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, q[0]) + __builtin_bit_cast(float, opaque_copy(q[1]));
+}
+
 // erf(z) ~= zc * Q(zc^2), zc = clamp(z, +-2.9), Q = degree-9 Chebyshev fit of erf(z)/z on [0, 2.9^2]:
 // |error| <= 4.2e-5 in erf (8.5e-5 in GELU, below the bf16 rounding of every consumer), pure FMA chain --
 // no v_exp / v_rcp (libm erff is ~40 instructions; the GELU epilogue of mlp.0 evaluates 94 M of these per

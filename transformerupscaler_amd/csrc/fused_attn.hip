@@ -258,39 +258,50 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         lds_wait<0>();
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- S^T = K Q^T + bias, softmax over keys, O^T = V^T P^T ----
+        // ---- S^T = K Q^T + bias, softmax over keys, O^T = V^T P^T; both query tiles advance in lockstep (independent chains
+        // cover each other's latencies), cross-lane reductions by v_permlane swaps instead of ds_bpermute, exp2 with the
+        // log2(e) scale and the row maximum folded into one FMA, P enters the product unnormalised and O is scaled by 1 / sum ----
+        f32x4 st[2][4];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) st[tg][kt] = mfma16x16x16(kf[kt], qf[tg], rb[tg][kt]);          // bias as the accumulator input
+        float mx[2], sum[2];
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) {
-            f32x4 st[4];
-            float mx = -INFINITY;
+            float m = fmaxf(fmaxf(st[tg][0][0], st[tg][0][1]), fmaxf(st[tg][0][2], st[tg][0][3]));
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                st[kt] = mfma16x16x16(kf[kt], qf[tg], rb[tg][kt]);          // bias as the accumulator input
+            for (int kt = 1; kt < 4; ++kt) m = fmaxf(fmaxf(m, st[tg][kt][0]), fmaxf(st[tg][kt][1], fmaxf(st[tg][kt][2], st[tg][kt][3])));
+            mx[tg] = m;
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[kt][e]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
+        for (int tg = 0; tg < 2; ++tg) mx[tg] = rows_max(mx[tg]) * 1.4426950408889634f;
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            float sm = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
+                for (int e = 0; e < 4; ++e) {
+                    st[tg][kt][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[tg][kt][e], 1.4426950408889634f, -mx[tg]));
+                    sm += st[tg][kt][e];
+                }
+            sum[tg] = sm;
+        }
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) sum[tg] = rows_sum(sum[tg]);
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
-                s16x4 pp[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const f32x4 pv = st[2 * kp + hh];
-                    // normalise before the bf16 rounding of P (softmax output is what the reference multiplies by v)
-                    pp[hh] = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(pv[0] * inv, pv[1] * inv), pack_bf16x2(pv[2] * inv, pv[3] * inv)});
-                }
-                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(pp[0], pp[1]), o);
+                const s16x4 p0 = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(st[tg][2 * kp][0], st[tg][2 * kp][1]), pack_bf16x2(st[tg][2 * kp][2], st[tg][2 * kp][3])});
+                const s16x4 p1 = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(st[tg][2 * kp + 1][0], st[tg][2 * kp + 1][1]), pack_bf16x2(st[tg][2 * kp + 1][2], st[tg][2 * kp + 1][3])});
+                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(p0, p1), o);
             }
+            const float inv = __builtin_amdgcn_rcpf(sum[tg]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= inv;
             // O^T tile: rows = channel 4g+e, column = query pl  ->  out[row][h*16 + 4g .. +3]
             if constexpr (PROJ) {
                 of[tg][h] = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])});

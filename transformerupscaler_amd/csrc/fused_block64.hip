@@ -15,6 +15,7 @@
 // Weight packing, LDS slot geometry, fragment addressing and the arithmetic order per token are those of fused_attn.hip: the
 // two kernels agree bit for bit (tests/test_hip_kernels.py::test_block64_equals_block32).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -29,7 +30,20 @@ struct Mlp64Args {
     const float* gamma2; const float* beta2;
     const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2;
 };
+// parameters of one WindowTransformerBlock (device pointers), the element type of the table tup_fused_blocks64_fwd takes
+struct Block64Ptrs {
+    const float* gamma1; const float* beta1; const bf16_t* wh; const float* bh; const float* bias_frag;
+    const bf16_t* wproj; const float* bproj; Mlp64Args ma;
+};
+static_assert(sizeof(Block64Ptrs) == 13 * 8, "table row = 13 device pointers");
+constexpr int MAX_BLK = 8;
+// passed BY VALUE: pointer fields of a kernel argument are global pointers to hipcc, pointers read from a table in memory are
+// generic (every load through them a flat_load, which counts on lgkmcnt AND vmcnt and drains the LDS-DMA queue at each use)
+struct Block64Table { Block64Ptrs b[MAX_BLK]; };
 
+template <class T> TUP_DEVICE const T* as_global(const T* p) {
+    return (const T*)(const __attribute__((address_space(1))) T*)p;
+}
 TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
     const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
     return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
@@ -38,10 +52,22 @@ TUP_DEVICE s16x4 pack4(f32x4 v) {
     return __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])});
 }
 
+// Diagnostic build only (STAMPS = true, TUP_B64_STAMPS=1): s_memtime at phase boundaries, summed per phase kind, for 8 recorded
+// workgroups (4 of the first dispatch round, 4 of the second); the values leave through a buffer nothing else reads.
+constexpr int NPH = 16;
+__device__ unsigned long long tup_b64_stamps[8][4][NPH];
+TUP_DEVICE unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+enum { PH_LN1 = 0, PH_SYNC0, PH_QKV, PH_HBAR, PH_ATT, PH_PROJ, PH_LN2, PH_MTOP, PH_FC1, PH_W2BAR, PH_GELU, PH_FC2, PH_STORE, PH_TOTAL };
+
+template <bool STAMPS>
 __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
-    float* __restrict__ xio, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const bf16_t* __restrict__ wh, const float* __restrict__ bh, const float* __restrict__ bias_frag,
-    int nwin, const bf16_t* __restrict__ wproj, const float* __restrict__ bproj, const Mlp64Args ma)
+    float* __restrict__ xio, const Block64Table tbl, int nblk, int nwin)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,6 +75,21 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
     const int win = blockIdx.x * 4 + wave;
     const bool active = win < nwin;
     const int row0 = (active ? win : nwin - 1) * 64;                    // first of this wave's 64 token rows
+    unsigned long long ph[NPH] = {}, tprev = 0, tstart = 0;
+    if constexpr (STAMPS) tprev = tstart = stamp_now();
+#define B64_STAMP(K) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now(); ph[K] += t_ - tprev; tprev = t_; } } while (0)
+
+    // All blocks of the model in ONE launch: a window never interacts with another window (the partition is the same in every
+    // block, model.py:283-289), so this wave carries its window through blk = 0 .. nblk-1; x goes through memory between
+    // blocks only as this wave's own store followed by its own loads (served by L2), and HBM sees x once in, once out.
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+    const Block64Ptrs& bp = tbl.b[blk];
+    const float* __restrict__ gamma = bp.gamma1; const float* __restrict__ beta = bp.beta1;
+    const bf16_t* __restrict__ wh = bp.wh; const float* __restrict__ bh = bp.bh; const float* __restrict__ bias_frag = bp.bias_frag;
+    const bf16_t* __restrict__ wproj = bp.wproj; const float* __restrict__ bproj = bp.bproj;
+    const Mlp64Args ma = bp.ma;
+    if (blk) __syncthreads();          // everyone is done with the previous block's LDS (weight slots, W2 chunk, biases)
 
     float* qb = reinterpret_cast<float*>(smem + QB_OFF);
     for (int i = tid; i < HEADS * 48; i += 256) qb[i] = bh[i];
@@ -135,6 +176,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
     const uint32_t sbase = lds_addr(smem);
     const uint32_t w_off = (uint32_t)swz128(pl, g);
     const uint32_t qb_addr = sbase + QB_OFF + (uint32_t)(4 * g) * 4;
+    B64_STAMP(PH_LN1);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of heads 0 / 1; bias staging visible below
     __syncthreads();
@@ -142,6 +184,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
     float vb[HEADS];
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) vb[h] = qb[h * 48 + 32 + pl];
+    B64_STAMP(PH_SYNC0);
 
     // the attention output of this wave's 64 tokens, all heads: of[tg][h] = O^T tile (channels 4g.., token pl) as bf16x4
     s16x4 of[TG][HEADS];
@@ -163,7 +206,8 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
         f32x4 acc[TG][3];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-            acc[0][ct] = __builtin_bit_cast(f32x4, lds_read_b128_asm(qb_addr + (uint32_t)((h * 48 + ct * 16) * 4)));
+            acc[0][ct] = __builtin_bit_cast(f32x4, lds_read_b128_asm_off(qb_addr, (h * 48 + ct * 16) * 4));    // immediate offsets: a
+            // per-head address register would be hoisted out of the block loop, spilled, and reloaded behind a vmcnt(0)
         {
             bf16x8 wf[3][3];
             auto ld = [&](int step, int slot) {
@@ -199,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        B64_STAMP(PH_QKV);
         // ONE barrier per head: it only recycles the weight slot.  Before it every wave waits for its own pieces of the NEXT
         // head's weights (requested a head ago; younger than them: the 16 bias loads above), so passing it means the next
         // head's weights have landed everywhere and everyone is done reading this head's slot, which is refilled two ahead.
@@ -207,42 +252,53 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
         if (h + 2 < HEADS) dma_w(h + 2, h & 1);
         else dma_wp(h + 2 - HEADS, h & 1);                      // proj chunks 0 and 1 take the place of "heads 12 and 13"
         __builtin_amdgcn_sched_barrier(0);
+        B64_STAMP(PH_HBAR);
 
         s16x4 kf[TG], vf[TG];
 #pragma unroll
         for (int kt = 0; kt < TG; ++kt) { kf[kt] = pack4(acc[kt][1]); vf[kt] = pack4(acc[kt][2]); }
-        // ---- S^T = K Q^T + bias, softmax over keys, O^T = V^T P^T ----
+        // ---- S^T = K Q^T + bias, softmax over keys, O^T = V^T P^T; the four query tiles advance in lockstep so that their
+        // (independent) MFMA -> max -> cross-lane -> exp -> sum chains cover each other's latencies ----
+        f32x4 st[TG][4];
 #pragma unroll
         for (int tg = 0; tg < TG; ++tg) {
             const s16x4 qf = pack4(acc[tg][0] * 0.25f);
-            f32x4 st[4];
-            float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                st[kt] = mfma16x16x16(kf[kt], qf, rb[tg][kt]);              // bias as the accumulator input
+            for (int kt = 0; kt < 4; ++kt) st[tg][kt] = mfma16x16x16(kf[kt], qf, rb[tg][kt]);      // bias as the accumulator input
+        }
+        float mx[TG], sum[TG];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, st[kt][e]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
+        for (int tg = 0; tg < TG; ++tg) {
+            float m = fmaxf(fmaxf(st[tg][0][0], st[tg][0][1]), fmaxf(st[tg][0][2], st[tg][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) m = fmaxf(fmaxf(m, st[tg][kt][0]), fmaxf(st[tg][kt][1], fmaxf(st[tg][kt][2], st[tg][kt][3])));
+            mx[tg] = m;
+        }
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) mx[tg] = rows_max(mx[tg]) * 1.4426950408889634f;
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
+            float sm = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
+                for (int e = 0; e < 4; ++e) {
+                    st[tg][kt][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[tg][kt][e], 1.4426950408889634f, -mx[tg]));
+                    sm += st[tg][kt][e];
+                }
+            sum[tg] = sm;
+        }
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) sum[tg] = rows_sum(sum[tg]);
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                s16x4 pp[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) pp[hh] = pack4(st[2 * kp + hh] * inv);   // normalise before the bf16 rounding of P
-                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(pp[0], pp[1]), o);
-            }
-            of[tg][h] = pack4(o);
+            for (int kp = 0; kp < 2; ++kp)        // P enters the product unnormalised (<= 1); O is scaled by 1 / sum in fp32
+                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(pack4(st[tg][2 * kp]), pack4(st[tg][2 * kp + 1])), o);
+            of[tg][h] = pack4(o * __builtin_amdgcn_rcpf(sum[tg]));
         }
+        B64_STAMP(PH_ATT);
     };
 #pragma unroll
     for (int h = 0; h < HEADS; ++h) head(h);               // unrolled: of[tg][h] must be a register, not an indexed array
@@ -291,6 +347,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    B64_STAMP(PH_PROJ);
     // ---- second half of the block.  acc2 <- the new residual stream x + proj + b_proj (inactive waves carry a copy of the
     // last window and take part in every barrier; only their final store is skipped) ----
 #pragma unroll
@@ -347,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
         }
     }
 
+    B64_STAMP(PH_LN2);
     // ---- MLP chunk loop: 64 hidden units per chunk j (two 32-unit halves s); W1 chunk j lives in slot (j + 1) & 1 ----
     const uint32_t w2_off0 = (uint32_t)(W2_OFF + swz128(pl, 2 * g)), w2_off1 = (uint32_t)(W2_OFF + swz128(pl, 2 * g + 1));
     const uint32_t b1_base = sbase + B1_OFF + (uint32_t)(g * 64);
@@ -357,6 +415,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
         const bool more = j + 1 < HID / 64;
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t wb1 = sbase + (uint32_t)(((j + 1) & 1) * FW_BYTES);
+        B64_STAMP(PH_MTOP);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f32x4 acc1[TG][2];
@@ -367,12 +426,13 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
             f32x4 bb[2];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh)
-                bb[hh] = __builtin_bit_cast(f32x4, lds_read_b128_asm(b1_base + (uint32_t)((j * 64 + (2 * s + hh) * 4) * 4)));
+                bb[hh] = __builtin_bit_cast(f32x4, lds_read_b128_asm_off(b1_base + (uint32_t)(j * 256), (2 * s + hh) * 16));
             bf16x8 wf[3][2];
+            const uint32_t wb1a = wb1 + w_off, wb1b = wb1 + (w_off ^ 64u);
             auto ld1 = [&](int step, int slot) {
-                const uint32_t a = wb1 + ((w_off ^ ((uint32_t)(step & 1) << 6)) + (uint32_t)((step >> 1) * (64 * 128) + 2 * s * 2048));
-                wf[slot][0] = lds_read_b128_asm(a);
-                wf[slot][1] = lds_read_b128_asm(a + 2048);
+                const uint32_t a = (step & 1) ? wb1b : wb1a;
+                wf[slot][0] = lds_read_b128_asm_off(a, (step >> 1) * (64 * 128) + 2 * s * 2048);
+                wf[slot][1] = lds_read_b128_asm_off(a, (step >> 1) * (64 * 128) + 2 * s * 2048 + 2048);
             };
             __builtin_amdgcn_sched_barrier(0);
             ld1(0, 0);
@@ -391,17 +451,18 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 if (s == 0 && more) { dma_w1_piece(j + 1, j & 1, step); __builtin_amdgcn_sched_barrier(0); }
             }
+            B64_STAMP(PH_FC1);
             if (s == 0) {
                 if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W2 chunk j landed (younger: the W1 prefetch)
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+            B64_STAMP(PH_W2BAR);
             bf16x8 w2f[8];
             const uint32_t w2a = sbase + (s ? w2_off1 : w2_off0);
-            auto w2addr = [&](int n) { return w2a + (uint32_t)((n >> 2) * (64 * 128) + (n & 3) * 2048); };
 #pragma unroll
-            for (int n = 0; n < 8; ++n) w2f[n] = lds_read_b128_asm(w2addr(n));
+            for (int n = 0; n < 8; ++n) w2f[n] = lds_read_b128_asm_off(w2a, (n >> 2) * (64 * 128) + (n & 3) * 2048);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 hfr[TG];
 #pragma unroll
@@ -419,6 +480,9 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
                 hfr[tg] = __builtin_bit_cast(bf16x8, pk);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STAMPS) {          // the stamp's lgkmcnt(0) drains the 8 W2 reads: re-issue nothing, just account GELU
+                const unsigned long long t_ = stamp_now(); ph[PH_GELU] += t_ - tprev; tprev = t_;
+            }
             lds_wait<4>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -427,7 +491,7 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
                 for (int tg = 0; tg < TG; ++tg) acc2[tg][n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][n]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) w2f[n] = lds_read_b128_asm(w2addr(8 + n));
+            for (int n = 0; n < 4; ++n) w2f[n] = lds_read_b128_asm_off(w2a, 2 * (64 * 128) + n * 2048);
             lds_wait<4>();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -442,32 +506,65 @@ __global__ __launch_bounds__(256, 1) void fused_block64_kernel(
 #pragma unroll
                 for (int tg = 0; tg < TG; ++tg) acc2[tg][8 + n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][8 + n]);
             __builtin_amdgcn_sched_barrier(0);
+            B64_STAMP(PH_FC2);
         }
     }
-    if (!active) return;
+    if (active) {
 #pragma unroll
-    for (int tg = 0; tg < TG; ++tg) {
-        float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+        for (int tg = 0; tg < TG; ++tg) {
+            float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
-        for (int n = 0; n < 12; ++n)
-            *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
+            for (int n = 0; n < 12; ++n)
+                *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
+        }
     }
+    }   // blk
+    if constexpr (STAMPS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        B64_STAMP(PH_STORE);
+        ph[PH_TOTAL] = tprev - tstart;
+        const int b = blockIdx.x;
+        const int rec = b < 4 ? b : (b >= 300 && b < 304 ? 4 + b - 300 : -1);
+        if (rec >= 0 && lane == 0)
+#pragma unroll
+            for (int k = 0; k < NPH; ++k) tup_b64_stamps[rec][wave][k] = ph[k];
+    }
+#undef B64_STAMP
 }
 
 }  // namespace
 
-// One whole WindowTransformerBlock, in place (model.py:153-172), one wave per window.  Same arguments, packing and
-// results as tup_fused_block_fwd (fused_attn.hip).
-extern "C" int tup_fused_block64_fwd(float* x, const float* gamma1, const float* beta1, const void* wh, const float* bh,
-                                     const float* bias_frag, const void* wproj, const float* bproj,
-                                     const float* gamma2, const float* beta2, const void* w1, const float* b1,
-                                     const void* w2, const float* b2, int nwin, void* stream)
+namespace {
+int launch_block64(float* x, const Block64Table& tbl, int nblk, int nwin, void* stream)
 {
-    if (nwin <= 0) return 0;
-    TUP_SET_DYN_LDS((fused_block64_kernel), B64_LDS);
-    const Mlp64Args ma{gamma2, beta2, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
-    fused_block64_kernel<<<dim3((nwin + 3) / 4), dim3(256), B64_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nwin, (const bf16_t*)wproj, bproj, ma);
+    static const bool stamps = getenv("TUP_B64_STAMPS") != nullptr;          // diagnostic build (timing shares only)
+    if (stamps) {
+        TUP_SET_DYN_LDS((fused_block64_kernel<true>), B64_LDS);
+        fused_block64_kernel<true><<<dim3((nwin + 3) / 4), dim3(256), B64_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, tbl, nblk, nwin);
+    } else {
+        TUP_SET_DYN_LDS((fused_block64_kernel<false>), B64_LDS);
+        fused_block64_kernel<false><<<dim3((nwin + 3) / 4), dim3(256), B64_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, tbl, nblk, nwin);
+    }
     TUP_CHECK_LAUNCH();
     return 0;
+}
+}  // namespace
+
+// nblk (<= 8) consecutive WindowTransformerBlocks, in place, in ONE launch (the loop of model.py:288-289), one wave per window.
+// table: HOST array [nblk][13] of device pointers in the argument order of tup_fused_block_fwd after x
+// (gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2), same packing.
+extern "C" int tup_fused_blocks64_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream)
+{
+    if (nwin <= 0 || nblk <= 0) return 0;
+    if (nblk > MAX_BLK || table == nullptr) return (int)hipErrorInvalidValue;
+    Block64Table t{};
+    static_assert(sizeof(Block64Ptrs) == 13 * sizeof(void*), "one table row = 13 pointers");
+    memcpy(&t, table, (size_t)nblk * sizeof(Block64Ptrs));
+    return launch_block64(x, t, nblk, nwin, stream);
+}
+
+// Timing experiments only: per-phase cycle sums of the last TUP_B64_STAMPS=1 launch, [8 workgroups][4 waves][16 phases].
+extern "C" int tup_debug_block64_stamps(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_b64_stamps), sizeof(unsigned long long) * 8 * 4 * NPH);
 }

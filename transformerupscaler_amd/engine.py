@@ -53,6 +53,12 @@ fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
+    if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and ops.block_tokens_per_wave == 64:
+        # all six blocks in ONE launch, one wave per window (csrc/fused_block64.hip)
+        table = ops.block_table([(pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
+                                  pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
+                                  pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)])
+        return ops.fused_blocks64(x, table)
     for i in range(BLOCKS):
         qkv = None
         if fuse_blocks and fuse_attention >= 3 and capture is None and f"b{i}.proj.wpp" in pk:

@@ -266,8 +266,35 @@ def fused_attn_block(x, gamma, beta, wh, bh, bias_frag, wproj, bproj):
     return x
 
 
-# which whole-block kernel runs: 64 = one wave per window (fused_block64.hip), 32 = two waves per window (fused_attn.hip)
-block_tokens_per_wave = int(os.environ.get("TUP_BLOCK_TOKENS_PER_WAVE", "64"))
+# which whole-block kernel runs: 32 = two waves per window, two workgroups per CU, one launch per block (fused_attn.hip; the
+# faster one: 198 vs 243 us per block at 1,920 windows, scripts/microbench_block.py); 64 = one wave per window, one workgroup
+# per CU, all blocks in one launch (fused_block64.hip; kept as the measured alternative)
+block_tokens_per_wave = int(os.environ.get("TUP_BLOCK_TOKENS_PER_WAVE", "32"))
+
+
+def block_table(blocks):
+    """Pointer table for tup_fused_blocks64_fwd: `blocks` = per block the 13 tensors (gamma1, beta1, wh, bh, bias_frag, wproj,
+    bproj, gamma2, beta2, w1, b1, w2, b2), validated here.  Returns (ctypes array [nblk*13] of device pointers, nblk, the tensors
+    -- kept alive by the caller holding the tuple)."""
+    import ctypes
+    shapes = [(F32, (192,)), (F32, (192,)), (BF16, (12, 64, 192)), (F32, (12, 48)), (F32, (12, 4, 4, 64, 4)), (BF16, (192, 192)),
+              (F32, (192,)), (F32, (192,)), (F32, (192,)), (BF16, (768, 192)), (F32, (768,)), (BF16, (192, 768)), (F32, (192,))]
+    if not 1 <= len(blocks) <= 8:
+        raise ValueError("1..8 blocks per launch")
+    ptrs = []
+    for blk in blocks:
+        assert len(blk) == 13
+        ptrs += [_chk(t, dt, sh, f"block operand {i}") for i, (t, (dt, sh)) in enumerate(zip(blk, shapes))]
+    return ((ctypes.c_void_p * len(ptrs))(*ptrs), len(blocks), [list(b) for b in blocks])
+
+
+def fused_blocks64(x, table):
+    """In place: the table's consecutive WindowTransformerBlocks in one launch, one wave per window (inference)."""
+    M = x.shape[0]
+    assert M % 64 == 0
+    arr, nblk, _keep = table
+    _lib.call("tup_fused_blocks64_fwd", _chk(x, F32, (M, 192), "x"), arr, nblk, M // 64, _stream())
+    return x
 
 
 def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2, tokens_per_wave=None):
@@ -275,7 +302,9 @@ def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2
     M = x.shape[0]
     assert M % 64 == 0
     tpw = block_tokens_per_wave if tokens_per_wave is None else tokens_per_wave
-    _lib.call("tup_fused_block64_fwd" if tpw == 64 else "tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
+    if tpw == 64:
+        return fused_blocks64(x, block_table([(gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2)]))
+    _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
               _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
               _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"),
               _chk(gamma2, F32, (192,), "gamma2"), _chk(beta2, F32, (192,), "beta2"),

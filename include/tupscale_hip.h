@@ -330,6 +330,19 @@ int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const
                         const float* gamma2, const float* beta2, const void* w1, const float* b1,
                         const void* w2, const float* b2, int nwin, void* stream);
 
+/* transforms.Resize on a uint8 PIL image (reference data_handling/data_class.py:61-71, inference.py:65-75) = Pillow's two-pass
+ * 8-bit BILINEAR resampler (third-party Pillow libImaging/Resample.c: triangle filter widened by the down-scale factor,
+ * weights normalised in double and rounded to 22 fractional bits, out = clip8((2^21 + sum(pixel * k)) >> 22), horizontal pass
+ * into a uint8 image first).  Bit-exact with Pillow.  Tables (device, int32) from resize_taps.pil_bilinear_coeffs:
+ * min / size [out], k [out][ksize].
+ * rows: src u8 [B][H][W][3] -> dst u8 [B][H][Wo][3]. */
+int tup_resize_u8_rows(const void* src, void* dst, const int* xmin, const int* xsize, const int* k, int ksize,
+                       int B, int H, int W, int Wo, void* stream);
+/* cols: src u8 [B][H][W][3] -> dst_u8 u8 [B][Ho][W][3] (or NULL) and / or dst_f32 fp32 [B][3][Ho][W] = value / 255 (or NULL;
+ * ToTensor fused, swap_rb = 1 for BGR frames). */
+int tup_resize_u8_cols(const void* src, void* dst_u8, float* dst_f32, const int* ymin, const int* ysize, const int* k,
+                       int ksize, int B, int H, int W, int Ho, int swap_rb, void* stream);
+
 /* nblk consecutive WindowTransformerBlocks in ONE launch with ONE WAVE PER WINDOW (64 tokens = four MFMA token tiles per wave,
  * one 256-thread workgroup per CU with the whole register file): replaces the loop `for block in self.window_blocks`,
  * model.py:288-289, with WindowTransformerBlock.forward :153-172 and WindowAttention.forward :104-133 inside.  K and V never

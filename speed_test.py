@@ -26,7 +26,7 @@ from tools.utils import get_latest_checkpoint, resolutions  # noqa: E402
 
 
 def load_frames(args, device):
-    h, w = resolutions[str(args.res_in)]
+    h, w = resolutions[str(args.source_res or args.res_in)]
     if args.data_dir:
         try:
             from PIL import Image
@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--graph", action="store_true", help="capture one frame (pre-process, model, post-process) into a hipGraph and replay it")
     ap.add_argument("--bgr", action="store_true", help="frames are BGR (screen grabs), output BGR")
+    ap.add_argument("--source_res", type=str, default=None, choices=list(resolutions),
+                    help="frames arrive at this resolution and are resized to --res_in on the GPU (transforms.Resize + ToTensor, "
+                         "bit-exact with Pillow: the LR transform of data_handling/data_class.py:61-64 and inference.py:65-68)")
     args = ap.parse_args()
 
     device = torch.device("cuda", 0)
@@ -73,8 +76,13 @@ def main():
     frames, source = load_frames(args, device)
     res_out = tuple(args.res_out)
 
+    lr_hw = resolutions[str(args.res_in)]
+
     def one_frame(frame_u8):
-        x = ops.frames_to_tensor(frame_u8, bgr=args.bgr)
+        if args.source_res and tuple(frame_u8.shape[:2]) != tuple(lr_hw):
+            x = ops.resize_frames(frame_u8, lr_hw, to_tensor=True, bgr=args.bgr)
+        else:
+            x = ops.frames_to_tensor(frame_u8, bgr=args.bgr)
         y = model(x, res_out=res_out)
         return ops.tensor_to_frames(y, bgr=args.bgr)
 
@@ -119,7 +127,8 @@ def main():
            "res_out": list(out.shape[1:3]), "graph": bool(args.graph),
            "latency_ms": {"mean": 1e3 * sum(lat) / len(lat), "p50": 1e3 * lat[len(lat) // 2], "p99": 1e3 * lat[min(len(lat) - 1, int(0.99 * len(lat)))]},
            "unsynced_launch_ms_mean": 1e3 * sum(launch) / len(launch), "images_per_sec": args.frames / wall,
-           "includes": "uint8 HWC -> model -> uint8 HWC on the GPU (no PCIe)"}
+           "includes": ("uint8 HWC -> Resize (Pillow-exact) -> model -> uint8 HWC on the GPU (no PCIe)" if args.source_res
+                        else "uint8 HWC -> model -> uint8 HWC on the GPU (no PCIe)")}
     print(json.dumps(res), flush=True)
 
 

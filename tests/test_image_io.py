@@ -73,3 +73,65 @@ def test_frame_path_under_hipgraph_replay_equals_eager():
         static_in.copy_(f1)
         g.replay(); torch.cuda.synchronize()
         assert torch.equal(static_out, eager1)
+
+
+# ---------------------------------------------------------------- uint8 Resize (transforms.Resize on a PIL image) --------------
+def _resize_cases(golden_dir):
+    import os
+    d = dict(np.load(os.path.join(golden_dir, "resize_pil_cases.npz")))
+    cases = [(d[f"in_{i}"], tuple(int(v) for v in d[f"size_{i}"]), d[f"out_{i}"]) for i in range(int(d["n"]))]
+    if "real_in" in d:
+        cases.append((d["real_in"], (72, 128), d["real_out"]))
+    return cases
+
+
+def test_resize_oracle_matches_pillow_fixtures(golden_dir):
+    """The numpy restatement of Pillow's 8-bit BILINEAR resampler against Pillow's own outputs (tests/golden/
+    make_golden_resize.py): every byte equal -- down- and up-scaling, one-axis-only, identity, aspect change, a real image."""
+    for img, size, ref in _resize_cases(golden_dir):
+        assert np.array_equal(IO.pil_resize_bilinear_u8(img, size), ref), (img.shape, size)
+
+
+def test_resize_oracle_matches_pillow_live():
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    for (H, W), (h, w) in [((180, 320), (60, 107)), ((45, 80), (135, 240)), ((17, 9), (5, 23))]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        assert np.array_equal(IO.pil_resize_bilinear_u8(img, (h, w)), np.asarray(Image.fromarray(img).resize((w, h), Image.BILINEAR)))
+
+
+def test_resize_tables_of_the_product_equal_the_oracles():
+    from transformerupscaler_amd.resize_taps import pil_bilinear_coeffs
+    for a, b in [(2160, 720), (3840, 1280), (1080, 720), (64, 96), (53, 31), (7, 7)]:
+        lo, n, k, ks = pil_bilinear_coeffs(a, b)
+        lo2, n2, k2, ks2 = IO.pil_bilinear_coeffs(a, b)
+        assert ks == ks2 and np.array_equal(lo, lo2) and np.array_equal(n, n2) and np.array_equal(k, k2)
+        assert (np.abs(k.sum(axis=1) - (1 << 22)) <= ks).all()              # weights sum to one (22 fractional bits)
+
+
+@pytest.mark.gpu
+def test_hip_resize_bit_exact_with_pillow(golden_dir):
+    from transformerupscaler_amd import ops
+    for img, size, ref in _resize_cases(golden_dir):
+        got = ops.resize_frames(torch.from_numpy(img).cuda(), size).cpu().numpy()
+        assert got.shape == (1,) + ref.shape
+        assert np.array_equal(got[0], ref), (img.shape, size)
+        # Resize + ToTensor in one pass == ToTensor of the resized bytes (data_class.py:61-64)
+        gt = ops.resize_frames(torch.from_numpy(img).cuda(), size, to_tensor=True).cpu().numpy()
+        assert np.array_equal(gt, IO.to_tensor(ref[None]))
+
+
+@pytest.mark.gpu
+def test_hip_resize_full_size_2160p_to_720p():
+    """The reference dataset's 4K -> 720p LR path (data_class.py:37) at full size, batch 2, against the oracle; BGR variant too."""
+    from transformerupscaler_amd import ops
+    f = frames((2, 2160, 3840, 3), 11)
+    got = ops.resize_frames(f.cuda(), (720, 1280)).cpu().numpy()
+    ref = IO.pil_resize_bilinear_u8(f.numpy(), (720, 1280))
+    assert np.array_equal(got, ref)
+    gt = ops.resize_frames(f[:1].cuda(), (720, 1280), to_tensor=True, bgr=True).cpu().numpy()
+    assert np.array_equal(gt, IO.to_tensor(ref[:1], bgr=True))
+    # constant images stay constant (weights sum to exactly 2^22 +- rounding: Pillow's own property)
+    c = torch.full((1, 300, 500, 3), 200, dtype=torch.uint8)
+    assert (ops.resize_frames(c.cuda(), (100, 170)).cpu() == 200).all()

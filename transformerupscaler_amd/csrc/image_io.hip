@@ -79,7 +79,88 @@ __global__ __launch_bounds__(256) void f32chw_to_u8hwc_kernel(const float* __res
     }
 }
 
+// ---- transforms.Resize on a uint8 image = Pillow's two-pass 8-bit resampler (reference data_handling/data_class.py:61-71,
+// inference.py:65-75).  Integer arithmetic, bit-exact with Pillow: out = clip8((2^21 + sum(pixel * k)) >> 22), k = the
+// normalised triangle weights with 22 fractional bits (tables from resize_taps.pil_bilinear_coeffs). ----
+constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
+TUP_DEVICE uint32_t clip8(int v) { v >>= PIL_PRECISION_BITS; return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// horizontal pass: src u8 [B][H][W][3] -> dst u8 [B][H][Wo][3]; a thread owns one output pixel (its taps are 3*n contiguous bytes)
+__global__ __launch_bounds__(256) void resize_u8_rows_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                             const int* __restrict__ xmin, const int* __restrict__ xsize,
+                                                             const int* __restrict__ kk, int ksize, int H, int W, int Wo)
+{
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (ox >= Wo || y >= H) return;
+    const uint8_t* s = src + ((size_t)((size_t)b * H + y) * W + xmin[ox]) * 3;
+    const int* k = kk + (size_t)ox * ksize;
+    const int n = xsize[ox];
+    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int i = 0; i < n; ++i) {
+        const int kv = k[i];
+        s0 += (int)s[3 * i] * kv; s1 += (int)s[3 * i + 1] * kv; s2 += (int)s[3 * i + 2] * kv;
+    }
+    uint8_t* d = dst + ((size_t)((size_t)b * H + y) * Wo + ox) * 3;
+    d[0] = (uint8_t)clip8(s0); d[1] = (uint8_t)clip8(s1); d[2] = (uint8_t)clip8(s2);
+}
+
+// vertical pass: src u8 [B][H][W][3] -> dst u8 [B][Ho][W][3] and / or fp32 planar [B][3][Ho][W] = value / 255 (ToTensor fused)
+__global__ __launch_bounds__(256) void resize_u8_cols_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst_u8,
+                                                             float* __restrict__ dst_f32, const int* __restrict__ ymin,
+                                                             const int* __restrict__ ysize, const int* __restrict__ kk, int ksize,
+                                                             int H, int W, int Ho, int swap_rb)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), oy = blockIdx.y * 4 + (threadIdx.x >> 6), b = blockIdx.z;
+    if (x >= W || oy >= Ho) return;
+    const uint8_t* s = src + ((size_t)((size_t)b * H + ymin[oy]) * W + x) * 3;
+    const int* k = kk + (size_t)oy * ksize;
+    const int n = ysize[oy];
+    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+    for (int i = 0; i < n; ++i) {
+        const int kv = k[i];
+        const uint8_t* r = s + (size_t)i * W * 3;
+        s0 += (int)r[0] * kv; s1 += (int)r[1] * kv; s2 += (int)r[2] * kv;
+    }
+    const uint32_t v0 = clip8(s0), v1 = clip8(s1), v2 = clip8(s2);
+    if (dst_u8) {
+        uint8_t* d = dst_u8 + ((size_t)((size_t)b * Ho + oy) * W + x) * 3;
+        d[0] = (uint8_t)v0; d[1] = (uint8_t)v1; d[2] = (uint8_t)v2;
+    }
+    if (dst_f32) {
+        const size_t hw = (size_t)Ho * W;
+        float* d = dst_f32 + (size_t)b * 3 * hw + (size_t)oy * W + x;
+        d[0] = (float)(swap_rb ? v2 : v0) / 255.0f; d[hw] = (float)v1 / 255.0f; d[2 * hw] = (float)(swap_rb ? v0 : v2) / 255.0f;
+    }
+}
+
 }  // namespace
+
+// Pillow's horizontal 8-bit resampling pass (Image.resize(..., BILINEAR) on an RGB image, the arithmetic behind
+// transforms.Resize on a PIL image: reference data_handling/data_class.py:61-71, inference.py:65-75).
+// src u8 [B][H][W][3] -> dst u8 [B][H][Wo][3]; xmin / xsize int32 [Wo], k int32 [Wo][ksize] (22 fractional bits).
+extern "C" int tup_resize_u8_rows(const void* src, void* dst, const int* xmin, const int* xsize, const int* k, int ksize,
+                                  int B, int H, int W, int Wo, void* stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || Wo <= 0) return 0;
+    if (B > 65535 || ksize < 1 || (H + 3) / 4 > 65535) return (int)hipErrorInvalidValue;
+    resize_u8_rows_kernel<<<dim3((Wo + 63) / 64, (H + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const uint8_t*)src, (uint8_t*)dst, xmin, xsize, k, ksize, H, W, Wo);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ... and its vertical pass, optionally fused with ToTensor: src u8 [B][H][W][3] -> dst_u8 u8 [B][Ho][W][3] (may be NULL) and /
+// or dst_f32 fp32 [B][3][Ho][W] = value / 255 (may be NULL; swap_rb = 1 reads BGR into RGB planes).
+extern "C" int tup_resize_u8_cols(const void* src, void* dst_u8, float* dst_f32, const int* ymin, const int* ysize, const int* k,
+                                  int ksize, int B, int H, int W, int Ho, int swap_rb, void* stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || Ho <= 0) return 0;
+    if (B > 65535 || ksize < 1 || (Ho + 3) / 4 > 65535 || (!dst_u8 && !dst_f32)) return (int)hipErrorInvalidValue;
+    resize_u8_cols_kernel<<<dim3((W + 63) / 64, (Ho + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        (const uint8_t*)src, (uint8_t*)dst_u8, dst_f32, ymin, ysize, k, ksize, H, W, Ho, swap_rb);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
 
 // src u8 [B][H][W][3] -> dst fp32 [B][3][H][W] = src / 255; swap_rb = 1 reads BGR frames (screen grabs) into RGB planes.
 extern "C" int tup_u8hwc_to_f32chw(const void* src, float* dst, int B, int H, int W, int swap_rb, void* stream)

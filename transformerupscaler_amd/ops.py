@@ -731,6 +731,44 @@ def tensor_to_frames(x, bgr=False):
     return out
 
 
+_PIL_TAPS = {}
+
+
+def _pil_taps_on(device, in_size, out_size):
+    from .resize_taps import pil_bilinear_coeffs
+    key = (str(device), in_size, out_size)
+    if key not in _PIL_TAPS:
+        lo, n, k, ks = pil_bilinear_coeffs(in_size, out_size)
+        _PIL_TAPS[key] = (torch.from_numpy(lo).to(device), torch.from_numpy(n).to(device), torch.from_numpy(k).to(device), ks)
+    return _PIL_TAPS[key]
+
+
+def resize_frames(frames_u8, size, to_tensor=False, bgr=False):
+    """transforms.Resize(size) on uint8 frames [B][H][W][3] (or [H][W][3]) on the GPU, bit-exact with Pillow's BILINEAR resample
+    of an RGB image (data_handling/data_class.py:61-71, inference.py:65-75).  to_tensor=False -> uint8 [B][h][w][3];
+    to_tensor=True -> fp32 [B][3][h][w] in [0, 1] (Resize + ToTensor in the same launches)."""
+    if frames_u8.dim() == 3:
+        frames_u8 = frames_u8.unsqueeze(0)
+    B, H, W, C = frames_u8.shape
+    assert C == 3
+    h, w = int(size[0]), int(size[1])
+    cur = frames_u8
+    _chk(cur, torch.uint8, None, "frames")
+    if w != W:                                            # Pillow: horizontal pass first, into a uint8 image
+        lo, n, k, ks = _pil_taps_on(cur.device, W, w)
+        tmp = torch.empty((B, H, w, 3), dtype=torch.uint8, device=cur.device)
+        _lib.call("tup_resize_u8_rows", cur.data_ptr(), tmp.data_ptr(), lo.data_ptr(), n.data_ptr(), k.data_ptr(), ks, B, H, W, w, _stream())
+        cur = tmp
+    if h != H:
+        lo, n, k, ks = _pil_taps_on(cur.device, H, h)
+        out_u8 = None if to_tensor else torch.empty((B, h, w, 3), dtype=torch.uint8, device=cur.device)
+        out_f = torch.empty((B, 3, h, w), dtype=F32, device=cur.device) if to_tensor else None
+        _lib.call("tup_resize_u8_cols", cur.data_ptr(), None if out_u8 is None else out_u8.data_ptr(),
+                  None if out_f is None else out_f.data_ptr(), lo.data_ptr(), n.data_ptr(), k.data_ptr(), ks, B, H, w, h, int(bgr), _stream())
+        return out_f if to_tensor else out_u8
+    return frames_to_tensor(cur, bgr=bgr) if to_tensor else (cur if cur is not frames_u8 else cur.clone())
+
+
 # ---- WindowTransformer (SURVEY 8(f) rank 2): window block at width 128 / 8 heads ----
 def relpos_bias_expand_h(table, heads):
     frag = torch.empty((heads, 4, 4, 64, 4), dtype=F32, device=table.device)

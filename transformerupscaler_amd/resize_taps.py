@@ -106,3 +106,36 @@ def transpose_taps(idx: np.ndarray, w: np.ndarray, in_size: int):
     start = np.zeros(in_size + 1, dtype=np.int32)
     start[1:] = np.cumsum(counts)
     return start, np.ascontiguousarray(flat_out[order].astype(np.int32)), np.ascontiguousarray(w.reshape(-1)[order].astype(np.float32))
+
+
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """Pillow's coefficient tables for an 8-bit BILINEAR resample of one axis (libImaging/Resample.c precompute_coeffs +
+    normalize_coeffs_8bpc; the arithmetic behind transforms.Resize on a PIL image, reference data_handling/data_class.py:61-71):
+    (min int32 [out], size int32 [out], k int32 [out][ksize], ksize).  Weights are computed and normalised in double and rounded
+    half away from zero to 22 fractional bits, exactly as Pillow does."""
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    lo = np.zeros(out_size, np.int32)
+    n = np.zeros(out_size, np.int32)
+    kk = np.zeros((out_size, ksize), np.float64)
+    inv = 1.0 / fscale
+    for i in range(out_size):
+        center = (i + 0.5) * scale
+        a = max(int(center - support + 0.5), 0)
+        b = min(int(center + support + 0.5), in_size)
+        ww = 0.0
+        for x in range(b - a):
+            t = abs((x + a - center + 0.5) * inv)
+            w = 1.0 - t if t < 1.0 else 0.0
+            kk[i, x] = w
+            ww += w
+        if ww != 0.0:
+            kk[i, :b - a] /= ww
+        lo[i], n[i] = a, b - a
+    ki = np.where(kk < 0, np.trunc(-0.5 + kk * (1 << PIL_PRECISION_BITS)), np.trunc(0.5 + kk * (1 << PIL_PRECISION_BITS)))
+    return lo, n, np.ascontiguousarray(ki.astype(np.int32)), ksize

@@ -153,7 +153,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # under torchrun also at N = 1: the RCCL path is then the one N ranks run
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
@@ -196,7 +196,7 @@ def main():
         tm = importlib.import_module("models.FastTransformer.model").TransformerModel()
         tm.load_state_dict(deterministic_state_dict(0), strict=False)
         tm = tm.to(dev).train()     # dropout p=0.1 active (model.py:80-82,127,132,150), as in train.py:109
-        dp = DataParallel(tm, scale=2) if world > 1 else None
+        dp = DataParallel(tm, scale=2) if dist is not None else None
         opt = harness.make_optimizer(tm, 1e-4)
         gt = torch.Generator().manual_seed(4321 + rank)
         lr = torch.rand((args.train_batch, 3, LR_H, LR_W), generator=gt).to(dev)
@@ -231,7 +231,7 @@ def main():
         tm = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
         tm.load_state_dict(rt_deterministic_state_dict(0))
         tm = tm.to(dev).train()                     # dropout p=0.1 on attention probabilities and MLP output
-        dp = DataParallel(tm) if world > 1 else None
+        dp = DataParallel(tm) if dist is not None else None
         opt = torch.optim.Adam(tm.parameters(), lr=1e-4)
         gt = torch.Generator().manual_seed(9876 + rank)
         lr = torch.rand((args.rt_batch, 3, LR_H, LR_W), generator=gt).to(dev)

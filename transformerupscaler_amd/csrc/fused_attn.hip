@@ -15,6 +15,7 @@
 // Every LDS access inside the head loop is inline asm: a compiler-visible LDS access behind an outstanding LDS-DMA makes
 // hipcc wait vmcnt(0); barriers are raw s_barrier with counted waits for the same reason.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -58,7 +59,20 @@ struct MlpArgs {
 constexpr int HID = 768;
 constexpr int M_W2_OFF = 2 * FW_BYTES, M_B1_OFF = 3 * FW_BYTES, FB_LDS = M_B1_OFF + HID * 4;       // 76,800 B
 
-template <bool PROJ, bool MLP = false>
+// Diagnostic build only (STAMPS = true, TUP_B32_STAMPS=1): s_memtime at phase boundaries, summed per phase kind, for 8 recorded
+// workgroups; the values leave through a buffer nothing else reads.
+constexpr int NPH32 = 16;
+__device__ unsigned long long tup_b32_stamps[8][4][NPH32];
+TUP_DEVICE unsigned long long stamp_now32() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+enum { P_LN1 = 0, P_SYNC0, P_QKV, P_HBAR, P_ATT, P_PROJ, P_LN2, P_MTOP, P_FC1, P_W2BAR, P_GELU, P_FC2, P_STORE, P_TOTAL };
+
+template <bool PROJ, bool MLP = false, bool STAMPS = false>
 __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const bf16_t* __restrict__ wh, const float* __restrict__ bh, const float* __restrict__ bias_frag,
@@ -73,6 +87,9 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const int win = blockIdx.x * 2 + wi;
     const bool active = win < nwin;
     const int row0 = (active ? win : nwin - 1) * 64 + 32 * hf;          // first of this wave's 32 token rows
+    unsigned long long ph[NPH32] = {}, tprev = 0, tstart = 0;
+    if constexpr (STAMPS) tprev = tstart = stamp_now32();
+#define B32_STAMP(K) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now32(); ph[K] += t_ - tprev; tprev = t_; } } while (0)
 
     float* qb = reinterpret_cast<float*>(smem + QB_OFF);
     for (int i = tid; i < HEADS * 48; i += 256) qb[i] = bh[i];
@@ -180,8 +197,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                                              (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
     };
 
+    B32_STAMP(P_LN1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of head 0's weights; bias staging visible below
     __syncthreads();
+    B32_STAMP(P_SYNC0);
     auto head = [&](const int h) {
         // relative position bias of this wave's (key tile, query tile) pairs, requested BEFORE the DMA below so that the
         // compiler's wait for them is vmcnt(6) (= the DMA pieces), not vmcnt(0)
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        B32_STAMP(P_QKV);
         // ---- q stays (scaled); K and V go to the window's LDS tile ----
         s16x4 qf[2];
         const uint32_t kvb = kv_win + (uint32_t)((h & 1) * 8192);
@@ -257,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         }
         lds_wait<0>();
         __builtin_amdgcn_sched_barrier(0);
+        B32_STAMP(P_HBAR);
 
         // ---- S^T = K Q^T + bias, softmax over keys, O^T = V^T P^T; both query tiles advance in lockstep (independent chains
         // cover each other's latencies), cross-lane reductions by v_permlane swaps instead of ds_bpermute, exp2 with the
@@ -310,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 *reinterpret_cast<u32x2*>(op) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             }
         }
+        B32_STAMP(P_ATT);
     };
     if constexpr (PROJ) {
 #pragma unroll
@@ -366,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        B32_STAMP(P_PROJ);
         if constexpr (!MLP) {
             if (!active) return;
 #pragma unroll
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 }
             }
 
+            B32_STAMP(P_LN2);
             // ---- the chunk loop of fused_mlp_v2_kernel (fused_blocks.hip); W1 chunk j lives in slot (j + 1) & 1 ----
             const uint32_t w2_off0 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g)), w2_off1 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g + 1));
             const uint32_t b1_base = sbase + M_B1_OFF + (uint32_t)(g * 64);
@@ -449,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 const bool more = j + 1 < HID / 64;
                 __builtin_amdgcn_sched_barrier(0);
                 const uint32_t wb1 = sbase + (uint32_t)(((j + 1) & 1) * FW_BYTES);
+                B32_STAMP(P_MTOP);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     f32x4 acc1[2][2];
@@ -460,7 +485,9 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
                         bb[hh] = __builtin_bit_cast(f32x4, lds_read_b128_asm(b1_base + (uint32_t)((j * 64 + (2 * s + hh) * 4) * 4)));
-                    bf16x8 wf[3][2];
+                    // fragments three K-steps ahead: a step is only 4 MFMAs (64 cycles) and an LDS read under load takes
+                    // 150-250 (stamps: FC1 ran at 3x its MFMA time with two steps of lookahead)
+                    bf16x8 wf[4][2];
                     auto ld1 = [&](int step, int slot) {
                         const uint32_t a = wb1 + ((w_off ^ ((uint32_t)(step & 1) << 6)) + (uint32_t)((step >> 1) * (64 * 128) + 2 * s * 2048));
                         wf[slot][0] = lds_read_b128_asm(a);
@@ -469,10 +496,12 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                     ld1(0, 0);
                     ld1(1, 1);
+                    ld1(2, 2);
 #pragma unroll
                     for (int step = 0; step < 6; ++step) {
-                        const int cur = step % 3;
-                        if (step + 2 < 6) { ld1(step + 2, (step + 2) % 3); lds_wait<4>(); }
+                        const int cur = step % 4;
+                        if (step + 3 < 6) { ld1(step + 3, (step + 3) % 4); lds_wait<6>(); }
+                        else if (step + 2 < 6) lds_wait<4>();
                         else if (step + 1 < 6) lds_wait<2>();
                         else lds_wait<0>();
                         __builtin_amdgcn_sched_barrier(0);
@@ -483,12 +512,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                         __builtin_amdgcn_sched_barrier(0);
                         if (s == 0 && more) { dma_w1_piece(j + 1, j & 1, step); __builtin_amdgcn_sched_barrier(0); }
                     }
+                    B32_STAMP(P_FC1);
                     if (s == 0) {
                         if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // W2 chunk j landed (younger: the W1 prefetch)
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                     }
+                    B32_STAMP(P_W2BAR);
                     bf16x8 w2f[8];
                     const uint32_t w2a = sbase + (s ? w2_off1 : w2_off0);
                     auto w2addr = [&](int n) { return w2a + (uint32_t)((n >> 2) * (64 * 128) + (n & 3) * 2048); };
@@ -511,6 +542,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                         hfr[tg] = __builtin_bit_cast(bf16x8, pk);
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    B32_STAMP(P_GELU);
                     lds_wait<4>();
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -534,6 +566,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                         for (int tg = 0; tg < 2; ++tg) acc2[tg][8 + n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][8 + n]);
                     __builtin_amdgcn_sched_barrier(0);
+                    B32_STAMP(P_FC2);
                 }
             }
             if (!active) return;
@@ -544,8 +577,19 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 for (int n = 0; n < 12; ++n)
                     *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
             }
+            if constexpr (STAMPS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                B32_STAMP(P_STORE);
+                ph[P_TOTAL] = tprev - tstart;
+                const int b = blockIdx.x;
+                const int rec = b < 4 ? b : (b >= 600 && b < 604 ? 4 + b - 600 : -1);
+                if (rec >= 0 && lane == 0)
+#pragma unroll
+                    for (int k = 0; k < NPH32; ++k) tup_b32_stamps[rec][wave][k] = ph[k];
+            }
         }
     }
+#undef B32_STAMP
 }
 
 }  // namespace
@@ -585,10 +629,24 @@ extern "C" int tup_fused_block_fwd(float* x, const float* gamma1, const float* b
                                    const void* w2, const float* b2, int nwin, void* stream)
 {
     if (nwin <= 0) return 0;
-    TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
     const MlpArgs ma{gamma2, beta2, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
+    static const bool stamps = getenv("TUP_B32_STAMPS") != nullptr;          // diagnostic build (timing shares only)
+    if (stamps) {
+        TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, true>), FB_LDS);
+        fused_qkv_attn_kernel<true, true, true><<<dim3((nwin + 1) / 2), dim3(256), FB_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
+            x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, ma);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
+    TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
     fused_qkv_attn_kernel<true, true><<<dim3((nwin + 1) / 2), dim3(256), FB_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
         x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, ma);
     TUP_CHECK_LAUNCH();
     return 0;
+}
+
+// Timing experiments only: per-phase cycle sums of the last TUP_B32_STAMPS=1 launch, [8 workgroups][4 waves][16 phases].
+extern "C" int tup_debug_block32_stamps(unsigned long long* host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_b32_stamps), sizeof(unsigned long long) * 8 * 4 * NPH32);
 }

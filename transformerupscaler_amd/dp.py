@@ -183,8 +183,9 @@ class GradReducer:
     def _launch(self, k: int) -> None:
         a, b = self.bucket_ranges[k]
         self.launched_order.append(k)
-        if self.world == 1 or b <= a:
-            return
+        if b <= a or not dist.is_initialized():
+            return                      # no process group: single process, nothing to reduce
+        # (a 1-rank group still issues its collectives: the RCCL / stream / event path is then the one N ranks run)
         view = self.flat[a:b]
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
@@ -208,7 +209,7 @@ class GradReducer:
         assert self._next_bucket == len(self.bucket_ranges)
         for w in self._works:
             w.wait()
-        if self.comm_stream is not None and self.world > 1:
+        if self.comm_stream is not None and dist.is_initialized():
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         self._works = []
         if self.world > 1:

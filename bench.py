@@ -156,7 +156,19 @@ def main():
     if world > 1 or "RANK" in os.environ:          # under torchrun also at N = 1: the RCCL path is then the one N ranks run
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on (C-level) stdout when its communicator comes up; the contract is ONE JSON line
+        # on stdout, so fd 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import importlib
     from transformerupscaler_amd import engine

@@ -330,7 +330,8 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
         hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<OCC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e; \
         tail_fused_kernel<OCC, ST><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p); } while (0)
-    if (stamps_on) TUP_TAIL_LAUNCH(4, true);
+    if (stamps_on && occ2) TUP_TAIL_LAUNCH(2, true);      // spill-free stamps (the <4, true> build spills 143 VGPRs: its shares mislead)
+    else if (stamps_on) TUP_TAIL_LAUNCH(4, true);
     else if (occ2) TUP_TAIL_LAUNCH(2, false);
     else TUP_TAIL_LAUNCH(4, false);
 #undef TUP_TAIL_LAUNCH

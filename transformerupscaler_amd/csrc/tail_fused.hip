@@ -12,7 +12,13 @@
 
 namespace {
 
-constexpr int OT_H = 16, OT_W = 64, NT = 512, NROW = NT / 64;     // 8 waves per workgroup
+#ifndef TUP_TAIL_OT_H
+#define TUP_TAIL_OT_H 16
+#endif
+// 16 x 64 output tiles, 8 waves, two workgroups per CU.  Measured alternatives (round 2, same box, rocprofv3): 8 x 64 tiles / 4
+// waves / four workgroups per CU 779 us, 32 x 64 tiles / 16 waves / one workgroup per CU 738 us, this geometry 685 us; with
+// 170 or 256 VGPRs instead of 128 (no scratch) every geometry is within 3 % of its 128-VGPR time.
+constexpr int OT_H = TUP_TAIL_OT_H, OT_W = 64, NT = 32 * OT_H, NROW = NT / 64;
 __device__ unsigned long long tup_tail_stamps[16];        // timing experiments (TUP_TAIL_STAMPS=1): s_memtime per stage, one workgroup
 
 struct TailParams {
@@ -323,8 +329,9 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     const int nfu = 3 * r * r;
     const size_t lds = ((size_t)nfu * 28 + ((nfu + 1) & ~1) + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW + 2) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, two 512-thread workgroups per CU) or 2
+    // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, 16 waves per CU) or 2
     static const bool occ2 = getenv("TUP_TAIL_OCC2") != nullptr;
+    static const bool occ3 = getenv("TUP_TAIL_OCC3") != nullptr;        // 170 VGPRs: no spills, three workgroups per CU
     dim3 grid((Wo + OT_W - 1) / OT_W, (Ho + OT_H - 1) / OT_H, B);
 #define TUP_TAIL_LAUNCH(OCC, ST) do { \
         hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<OCC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -333,6 +340,7 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     if (stamps_on && occ2) TUP_TAIL_LAUNCH(2, true);      // spill-free stamps (the <4, true> build spills 143 VGPRs: its shares mislead)
     else if (stamps_on) TUP_TAIL_LAUNCH(4, true);
     else if (occ2) TUP_TAIL_LAUNCH(2, false);
+    else if (occ3) TUP_TAIL_LAUNCH(3, false);
     else TUP_TAIL_LAUNCH(4, false);
 #undef TUP_TAIL_LAUNCH
     TUP_CHECK_LAUNCH();

@@ -153,6 +153,9 @@ def resize_aa(x, size, clamp=False):
     return out
 
 
+TAIL_TILE_H = 16          # = OT_H of csrc/tail_fused.hip
+
+
 def tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True):
     """Last final_upscale stage + final_upscale_conv + "+ upscaled_input" + Resize(out_hw) + clamp in one kernel."""
     from .resize_taps import taps_or_identity, tile_extent
@@ -166,7 +169,7 @@ def tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True):
         d = x.device
         _TAP_CACHE[key] = (torch.from_numpy(ylo).to(d), torch.from_numpy(yn).to(d), torch.from_numpy(np.ascontiguousarray(yw)).to(d), ky,
                            torch.from_numpy(xlo).to(d), torch.from_numpy(xn).to(d), torch.from_numpy(np.ascontiguousarray(xw)).to(d), kx,
-                           tile_extent(Hs, Ho, 16), tile_extent(Ws, Wo, 64))
+                           tile_extent(Hs, Ho, TAIL_TILE_H), tile_extent(Ws, Wo, 64))
     ylo, yn, yw, ky, xlo, xn, xw, kx, eh, ew = _TAP_CACHE[key]
     out = torch.empty((B, 3, Ho, Wo), dtype=F32, device=x.device)
     _lib.call("tup_tail_fused_fwd", _chk(x, F32, None, "x"), _chk(wfu, F32, (3 * r * r, 28), "wfu"), _chk(bfu, F32, (3 * r * r,), "bfu"),

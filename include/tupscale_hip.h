@@ -330,6 +330,22 @@ int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const
                         const float* gamma2, const float* beta2, const void* w1, const float* b1,
                         const void* w2, const float* b2, int nwin, void* stream);
 
+/* Branch A in TRAINING through its exact composition (r = 2): replaces autograd through `self.up1(feat)` + `self.up1_conv(...)`,
+ * model.py:264-265 (Upsampler utils.py:62-63 + BasicConv utils.py:32-40; no non-linearity between the two convs, utils.py:50).
+ * compose: wu fp32 [256][64][3][3], bu fp32 [256], w3 fp32 [3][64][3][3] -> the composed 5x5 conv's weights in every layout the
+ * kernels use: wv bf16 [9 border variants][12 n][25 taps][64] + bv fp32 [9][12]; wp bf16 [25][16][64] (forward main kernel,
+ * zero-initialised by the caller); wd bf16 [13][64][32] (input-gradient kernel, zero-initialised by the caller). */
+int tup_bra_compose(const float* wu, const float* bu, const float* w3, void* wv, float* bv, void* wp, void* wd, void* stream);
+/* backward: g fp32 [B][3][2H][2W] (gradient w.r.t. upscaled_input, before its ReLU mask), ui fp32 [B][3][2H][2W], feat bf16
+ * [B][H][W][64] -> dfeat bf16 [B][H][W][64] (written); G fp32 [9][12][25][64], Gb fp32 [9][12] = gradient w.r.t. the composed
+ * weights / biases per variant (ACCUMULATED: zero first); g12 bf16 [B][H][W][16] workspace.  H, W >= 6. */
+int tup_bra_backward(const float* g, const float* ui, const void* feat, const void* wd, const void* wv,
+                     void* g12, void* dfeat, float* G, float* Gb, int B, int H, int W, void* stream);
+/* chain rule through the composition: G, Gb -> dwu fp32 [256][64][3][3], dbu fp32 [256], dw3 fp32 [3][64][3][3] (written);
+ * dM fp32 [62208] and dMb fp32 [108] workspaces. */
+int tup_bra_chain(const float* G, const float* Gb, const float* wu, const float* bu, const float* w3,
+                  float* dM, float* dMb, float* dwu, float* dbu, float* dw3, void* stream);
+
 /* transforms.Resize on a uint8 PIL image (reference data_handling/data_class.py:61-71, inference.py:65-75) = Pillow's two-pass
  * 8-bit BILINEAR resampler (third-party Pillow libImaging/Resample.c: triangle filter widened by the down-scale factor,
  * weights normalised in double and rounded to 22 fractional bits, out = clip8((2^21 + sum(pixel * k)) >> 22), horizontal pass

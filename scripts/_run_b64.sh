@@ -1,2 +1,5 @@
-timeout -k 10 400 python -m pytest tests/test_hip_kernels.py -m gpu -q -s -p no:cacheprovider -k "block or fused" > gpurun_out/r2_t2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r2_t2.log; grep -E "passed|failed|rc=|^E " gpurun_out/r2_t2.log | head -20; grep -q "rc=0" gpurun_out/r2_t2.log && timeout -k 10 200 python scripts/microbench_block.py > gpurun_out/r2_mb1.log 2>&1; cat gpurun_out/r2_mb1.log | tail -4
-timeout -k 10 200 python scripts/_block32_stamps.py 2>&1 | grep -E "wg [05] wave 0"
+timeout -k 10 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "train or grads or dp or parity or per_sample or adam" > gpurun_out/r2_t2.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r2_t2.log; grep -E "passed|failed|rc=|^E " gpurun_out/r2_t2.log | head -30
+timeout -k 10 300 python bench.py --mode train --steps 10 --warmup 3 > gpurun_out/r2_train1.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/r2_train1.json')); print('train', d['value'], d['ms_per_step'], d['loss'])"
+TUP_NO_COMPOSED_TRAIN=1 timeout -k 10 300 python bench.py --mode train --steps 10 --warmup 3 > gpurun_out/r2_train0.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/r2_train0.json')); print('train explicit', d['value'], d['ms_per_step'], d['loss'])"

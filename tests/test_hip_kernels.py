@@ -602,3 +602,36 @@ def test_blocks64_six_in_one_launch_equals_six_launches(dev):
         ops.fused_block(ref, *a, tokens_per_wave=64)
     assert torch.isfinite(one).all()
     assert torch.equal(one, ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 8, 32), (1, 13, 37), (2, 24, 70), (1, 6, 6)])
+def test_branch_a_composed_training(dev, B, H, W):
+    """csrc/branch_a_train.hip: forward of the composed branch A and its whole backward (input gradient incl. the ring, the
+    gradient w.r.t. the composed weights, the chain rule to W_up / b_up / W_3) against torch autograd through the explicit
+    chain conv 64->256 -> PixelShuffle(2) -> conv 64->3 (no bias) -> ReLU (model.py:264-265)."""
+    from transformerupscaler_amd import ops
+    g_ = torch.Generator().manual_seed(31 + H)
+    feat = bf(torch.randn((B, 64, H, W), generator=g_) * 0.7).requires_grad_(True)
+    wu = (torch.randn((256, 64, 3, 3), generator=g_) * 0.04).requires_grad_(True)
+    bu = (torch.randn((256,), generator=g_) * 0.1).requires_grad_(True)
+    w3 = (torch.randn((3, 64, 3, 3), generator=g_) * 0.04).requires_grad_(True)
+    pre = F.conv2d(F.pixel_shuffle(F.conv2d(feat, wu, bu, padding=1), 2), w3, None, padding=1)
+    ui = F.relu(pre)
+    gout = torch.randn(ui.shape, generator=g_)
+    ui.backward(gout)
+    comp = ops.bra_compose(wu.detach().to(dev), bu.detach().to(dev), w3.detach().to(dev))
+    fnhwc = feat.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+    got_ui = ops.branch_a_composed(fnhwc, comp["wp"], comp["bias"], comp["wv"], comp["bv"], 2)
+    close(got_ui, ui.detach(), 3e-2, 2e-2, "composed forward (training weights)")
+    # the backward is evaluated at the REFERENCE's ReLU gates so that only the kernels are compared
+    dfeat, dwu, dbu, dw3, G, Gb = ops.bra_backward(gout.to(dev), ui.detach().to(dev), fnhwc, comp, wu.detach().to(dev), bu.detach().to(dev), w3.detach().to(dev))
+    def rel(a, b):
+        return ((a.float().cpu() - b).norm() / b.norm().clamp_min(1e-12)).item()
+    r_f = rel(dfeat.permute(0, 3, 1, 2), feat.grad)
+    r_u, r_b, r_3 = rel(dwu, wu.grad), rel(dbu, bu.grad), rel(dw3, w3.grad)
+    print(f"B{B} {H}x{W}: rel L2 dfeat {r_f:.4f} dW_up {r_u:.4f} db_up {r_b:.4f} dW_3 {r_3:.4f}")
+    # ring rows / columns of d feat separately (they come from the variant kernels)
+    frame = torch.ones((H, W), dtype=torch.bool); frame[3:-3, 3:-3] = False
+    fr = rel(dfeat.permute(0, 3, 1, 2)[..., frame], feat.grad[..., frame])
+    assert max(r_f, fr) <= 2e-2, (r_f, fr)
+    assert r_u <= 2e-2 and r_b <= 2e-2 and r_3 <= 2e-2, (r_u, r_b, r_3)

@@ -62,6 +62,9 @@ SIGNATURES = {
     "tup_l1_loss_bwd": [P, P, P, P, c_longlong, P],
     "tup_u8hwc_to_f32chw": [P, P, I, I, I, I, P],
     "tup_f32chw_to_u8hwc": [P, P, I, I, I, I, P],
+    "tup_bra_compose": [P, P, P, P, P, P, P, P],
+    "tup_bra_backward": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "tup_bra_chain": [P, P, P, P, P, P, P, P, P, P, P],
     "tup_resize_u8_rows": [P, P, P, P, P, I, I, I, I, I, P],
     "tup_resize_u8_cols": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "tup_rt_bicubic_sum_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P],

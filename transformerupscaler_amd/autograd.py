@@ -50,11 +50,19 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, see
     sv["x"] = x
     sv["feat1"] = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
     feat = sv["feat"] = ops.conv_c64(sv["feat1"], pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+    stages = upsampler_layout(scale)
     ups = [feat]
-    for si, (_, r) in enumerate(upsampler_layout(scale)):
+    # the last Upsampler stage + up1_conv through their exact composition (csrc/branch_a_train.hip) when it is a x2 stage:
+    # one 5x5 conv with 12 outputs instead of the 64 -> 256 conv, the 64-channel HR tensor and the 64 -> 3 conv
+    composed = "bra.comp" in pk and stages[-1][1] == 2 and min(H, W) * (scale // 2) >= 6
+    for si, (_, r) in enumerate(stages[:-1] if composed else stages):
         ups.append(ops.conv_c64(ups[-1], pk[f"up1.{si}.w"], pk[f"up1.{si}.b"], r, relu=False))
-    sv["ups"] = ups
-    ui = sv["ui"] = ops.conv_c64_thin(ups[-1], pk["up1_conv.w"], None, 3, relu=True)
+    sv["ups"], sv["bra"] = ups, composed
+    if composed:
+        c = pk["bra.comp"]
+        ui = sv["ui"] = ops.branch_a_composed(ups[-1], c["wp"], c["bias"], c["wv"], c["bv"], 2, relu=True)
+    else:
+        ui = sv["ui"] = ops.conv_c64_thin(ups[-1], pk["up1_conv.w"], None, 3, relu=True)
     xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])
     blocks = []
     for i in range(BLOCKS):
@@ -175,13 +183,22 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
     del g_x
     ready("patch_embed.weight", "patch_embed.bias")
     # ---- branch A: up1_conv (ReLU, no bias) and the Upsampler stages ----
-    g_ui = ops.mask_bwd(g_sum, relu_src=ui)
     ups = sv["ups"]
-    dwp, _ = ops.conv_thin_wgrad(ups[-1], g_ui, False)
-    g["up1_conv.conv.weight"] = dwp.permute(0, 2, 1).reshape(3, 64, 3, 3)
-    g_up = ops.conv1(g_ui, pk["up1_conv.wd"], None, relu=False)
-    ready("up1_conv.conv.weight")
-    for si in reversed(range(len(stages))):
+    nexp = len(stages)                 # stages whose backward runs through the explicit conv kernels
+    if sv["bra"]:
+        idx, _ = stages[-1]
+        k = f"up1.upsamplers.{scale}.{idx}"
+        g_up, g[k + ".weight"], g[k + ".bias"], g["up1_conv.conv.weight"] = ops.bra_backward(
+            g_sum, ui, ups[-1], pk["bra.comp"], pk["bra.wu"], pk["bra.bu"], pk["bra.w3"])[:4]
+        ready("up1_conv.conv.weight", k + ".weight", k + ".bias")
+        nexp -= 1
+    else:
+        g_ui = ops.mask_bwd(g_sum, relu_src=ui)
+        dwp, _ = ops.conv_thin_wgrad(ups[-1], g_ui, False)
+        g["up1_conv.conv.weight"] = dwp.permute(0, 2, 1).reshape(3, 64, 3, 3)
+        g_up = ops.conv1(g_ui, pk["up1_conv.wd"], None, relu=False)
+        ready("up1_conv.conv.weight")
+    for si in reversed(range(nexp)):
         idx, r = stages[si]
         k = f"up1.upsamplers.{scale}.{idx}"
         dwp, db = ops.conv_c64_wgrad(ups[si], g_up, r)

@@ -9,6 +9,7 @@ reference models/FastTransformer/model.py:174-327 (+ utils.py:43-98), so ``train
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -16,6 +17,10 @@ import torch.nn as nn
 
 from . import engine, ops, packing
 from .weights import VALID_SCALES, upsampler_layout
+
+
+# training: run the last x2 Upsampler stage + up1_conv (and their backward) through the exact composition; False = explicit kernels
+compose_branch_a_in_training = not os.environ.get("TUP_NO_COMPOSED_TRAIN")
 
 
 class _ConvParams(nn.Module):
@@ -167,6 +172,14 @@ class TransformerModel(nn.Module):
             nb = len(self.window_blocks)
             frags_t = [ops.relpos_bias_expand(pk[f"b{i}.table"]) for i in range(nb)]
             frags_n = [ops.relpos_bias_expand_n(pk[f"b{i}.table"]) for i in range(nb)] if backward else None
+            if backward and compose_branch_a_in_training:
+                from .weights import upsampler_layout as _layout
+                idx, r = _layout(scale)[-1]
+                if r == 2:         # training: last Upsampler stage + up1_conv as one composed conv (csrc/branch_a_train.hip)
+                    k = f"up1.upsamplers.{scale}.{idx}"
+                    pk["bra.wu"], pk["bra.bu"] = sd[k + ".weight"].detach().float().contiguous(), sd[k + ".bias"].detach().float().contiguous()
+                    pk["bra.w3"] = sd["up1_conv.conv.weight"].detach().float().contiguous()
+                    pk["bra.comp"] = ops.bra_compose(pk["bra.wu"], pk["bra.bu"], pk["bra.w3"])
             hit = (ver, pk, frags_t, frags_n)
             self._pack_cache = {key: hit}
         return (hit[1], hit[2], hit[3]) if backward else (hit[1], hit[2])

@@ -734,6 +734,43 @@ def tensor_to_frames(x, bgr=False):
     return out
 
 
+# ---- branch A in training through its composition (csrc/branch_a_train.hip), r = 2 ----
+def bra_compose(wu, bu, w3):
+    """Composed weights of (Conv2d(64, 256, 3) + PixelShuffle(2) + Conv2d(64, 3, 3, bias=False)) in the kernels' layouts:
+    dict(wp, bias, wv, bv, wd)."""
+    dev = wu.device
+    wv = torch.empty((9, 12, 25, 64), dtype=BF16, device=dev)
+    bv = torch.empty((9, 12), dtype=F32, device=dev)
+    wp = torch.zeros((1, 1, 25, 16, 64), dtype=BF16, device=dev)
+    wd = torch.zeros((13, 64, 32), dtype=BF16, device=dev)
+    _lib.call("tup_bra_compose", _chk(wu, F32, (256, 64, 3, 3), "wu"), _chk(bu, F32, (256,), "bu"), _chk(w3, F32, (3, 64, 3, 3), "w3"),
+              wv.data_ptr(), bv.data_ptr(), wp.data_ptr(), wd.data_ptr(), _stream())
+    return {"wp": wp, "bias": bv[0].contiguous(), "wv": wv, "bv": bv, "wd": wd}
+
+
+def bra_backward(g, ui, feat, comp, wu, bu, w3):
+    """g: fp32 [B][3][2H][2W] gradient w.r.t. upscaled_input (pre-mask), ui: upscaled_input, feat: bf16 [B][H][W][64].
+    Returns (dfeat bf16 [B][H][W][64], dwu, dbu, dw3)."""
+    B, H, W, C = feat.shape
+    assert C == 64 and tuple(g.shape) == (B, 3, 2 * H, 2 * W)
+    dev = feat.device
+    g12 = torch.empty((B, H, W, 16), dtype=BF16, device=dev)
+    dfeat = torch.empty((B, H, W, 64), dtype=BF16, device=dev)
+    G = _zeros((9, 12, 25, 64), dev)
+    Gb = _zeros((9, 12), dev)
+    _lib.call("tup_bra_backward", _chk(g, F32, None, "g"), _chk(ui, F32, g.shape, "ui"), _chk(feat, BF16, None, "feat"),
+              _chk(comp["wd"], BF16, (13, 64, 32), "wd"), _chk(comp["wv"], BF16, (9, 12, 25, 64), "wv"),
+              g12.data_ptr(), dfeat.data_ptr(), G.data_ptr(), Gb.data_ptr(), B, H, W, _stream())
+    dM = torch.empty((3 * 9 * 4 * 9 * 64,), dtype=F32, device=dev)
+    dMb = torch.empty((108,), dtype=F32, device=dev)
+    dwu = torch.empty((256, 64, 3, 3), dtype=F32, device=dev)
+    dbu = torch.empty((256,), dtype=F32, device=dev)
+    dw3 = torch.empty((3, 64, 3, 3), dtype=F32, device=dev)
+    _lib.call("tup_bra_chain", G.data_ptr(), Gb.data_ptr(), _chk(wu, F32, (256, 64, 3, 3), "wu"), _chk(bu, F32, (256,), "bu"),
+              _chk(w3, F32, (3, 64, 3, 3), "w3"), dM.data_ptr(), dMb.data_ptr(), dwu.data_ptr(), dbu.data_ptr(), dw3.data_ptr(), _stream())
+    return dfeat, dwu, dbu, dw3, G, Gb
+
+
 _PIL_TAPS = {}
 
 

@@ -337,11 +337,12 @@ int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const
  * zero-initialised by the caller); wd bf16 [13][64][32] (input-gradient kernel, zero-initialised by the caller). */
 int tup_bra_compose(const float* wu, const float* bu, const float* w3, void* wv, float* bv, void* wp, void* wd, void* stream);
 /* backward: g fp32 [B][3][2H][2W] (gradient w.r.t. upscaled_input, before its ReLU mask), ui fp32 [B][3][2H][2W], feat bf16
- * [B][H][W][64] -> dfeat bf16 [B][H][W][64] (written); G fp32 [9][12][25][64], Gb fp32 [9][12] = gradient w.r.t. the composed
- * weights / biases per variant (ACCUMULATED: zero first); g12 bf16 [B][H][W][16] workspace.  H, W >= 6. */
+ * [B][H][W][64] -> dfeat bf16 [B][H][W][64] (written); G fp32 [16][9][12][25][64], Gb fp32 [16][9][12] = gradient w.r.t. the
+ * composed weights / biases per variant, spread over 16 replicas against atomic contention (ACCUMULATED: zero first; the
+ * gradient is the sum over the replicas); g12 bf16 [B][H][W][16] workspace.  H, W >= 6. */
 int tup_bra_backward(const float* g, const float* ui, const void* feat, const void* wd, const void* wv,
                      void* g12, void* dfeat, float* G, float* Gb, int B, int H, int W, void* stream);
-/* chain rule through the composition: G, Gb -> dwu fp32 [256][64][3][3], dbu fp32 [256], dw3 fp32 [3][64][3][3] (written);
+/* chain rule through the composition: G, Gb (16 replicas each, summed here) -> dwu fp32 [256][64][3][3], dbu fp32 [256], dw3 fp32 [3][64][3][3] (written);
  * dM fp32 [62208] and dMb fp32 [108] workspaces. */
 int tup_bra_chain(const float* G, const float* Gb, const float* wu, const float* bu, const float* w3,
                   float* dM, float* dMb, float* dwu, float* dbu, float* dw3, void* stream);

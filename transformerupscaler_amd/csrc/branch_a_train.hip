@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int NOUT = 12, NV = 9, NTAP = 25;
+// G / Gb are accumulated with float atomics from every workgroup into the same ~170 k addresses: REP replicas (chosen by the
+// workgroup id) cut the contention REP-fold (one replica: the ring kernel alone took 0.43 ms); the chain rule sums them
+constexpr int REP = 16, GSZ = NV * NOUT * NTAP * 64, GBSZ = NV * NOUT;
 
 TUP_DEVICE bool dropped(int mode, int d) { return (mode == 1 && d == 0) || (mode == 2 && d == 2); }
 
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void bra_prep_kernel(const float* __restrict__
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][n] = t;
     }
     __syncthreads();
-    if (threadIdx.x < NOUT) atomicAdd(gb0 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < NOUT) atomicAdd(gb0 + (blockIdx.x % REP) * GBSZ + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---- input gradient, main part: d feat[y][x][ci] = sum_{t', n} wd[ci][t'][n] g12[y + uy][x + ux][n], (uy, ux) = (t'/5 - 2, t'%5 - 2).
@@ -346,13 +349,14 @@ __global__ __launch_bounds__(256, 2) void bra_wgrad_kernel(const bf16_t* __restr
                 for (int cit = 0; cit < 4; ++cit)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        atomicAdd(G0 + ((size_t)(4 * g + e) * NTAP + wave + 4 * a) * 64 + 16 * cit + l16, acc[a][cit][e]);
+                        atomicAdd(G0 + (size_t)(blockIdx.x % REP) * GSZ + ((size_t)(4 * g + e) * NTAP + wave + 4 * a) * 64 + 16 * cit + l16, acc[a][cit][e]);
     }
 }
 
 // ---- weight gradient, ring part: G[v][n][t][ci] (v = 1..8) and Gb[v][n] from the HR ring pixels.  A workgroup owns a run of
-// up to 128 ring pixels (thread = channel x tap group); partial sums per (variant-of-pixel, n, tap) go out as atomics -- the
-// run is cut so that all its pixels share one variant. ----
+// RING_RUN ring pixels (thread = channel x tap group); partial sums per (variant-of-pixel, n, tap) go out as atomics -- the
+// run is cut so that all its pixels share one variant.  32-pixel runs: ~1,000 workgroups at 4 x 720p. ----
+constexpr int RING_RUN = 32;
 __global__ __launch_bounds__(256) void bra_wgrad_ring_kernel(const float* __restrict__ g, const float* __restrict__ ui,
                                                              const bf16_t* __restrict__ x, float* __restrict__ G, float* __restrict__ Gb,
                                                              int B, int H, int W)
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) void bra_wgrad_ring_kernel(const float* __rest
     const int per_img = 2 * Ws + 2 * (Hs - 2);
     const int ci = threadIdx.x & 63, tg = threadIdx.x >> 6;
     const int ntap = (tg == 0) ? 7 : 6;
-    const long long k0 = (long long)blockIdx.x * 128;
+    const long long k0 = (long long)blockIdx.x * RING_RUN;
     float acc[7][3];
     int cur_v = -1, cur_sp = -1;
     auto flush = [&]() {
@@ -371,44 +375,55 @@ __global__ __launch_bounds__(256) void bra_wgrad_ring_kernel(const float* __rest
             if (a < ntap)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    atomicAdd(G + (((size_t)cur_v * NOUT + c * 4 + cur_sp) * NTAP + tg + 4 * a) * 64 + ci, acc[a][c]);
+                    atomicAdd(G + (size_t)(blockIdx.x % REP) * GSZ + (((size_t)cur_v * NOUT + c * 4 + cur_sp) * NTAP + tg + 4 * a) * 64 + ci, acc[a][c]);
     };
-    // two passes over the run, one per sub-pixel phase parity along the run, so that (variant, phase) changes rarely
+    // two passes over the run, one per sub-pixel phase parity along the run, so that (variant, phase) changes rarely; the pixels go
+    // four at a time with all their loads issued before the first use (one pixel per iteration paid a global round trip each)
     for (int pass = 0; pass < 2; ++pass) {
-        for (int i = 0; i < 128; ++i) {
-            const long long gid = k0 + i;
-            if (gid >= (long long)per_img * B) break;
-            const int b = (int)(gid / per_img);
-            int Y, X;
-            ring_pixel((int)(gid - (long long)b * per_img), Hs, Ws, Y, X);
-            const int sp = (Y & 1) * 2 + (X & 1);
-            if (((Y + X) & 1) != pass) continue;
-            const int v = variant_of(Y, X, Hs, Ws);
-            if (v != cur_v || sp != cur_sp) {
-                flush();
-                cur_v = v; cur_sp = sp;
+        for (int i0 = 0; i0 < RING_RUN; i0 += 4) {
+            int vv[4], spp[4];
+            float gv[4][3], f[4][7];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long gid = k0 + i0 + j;
+                ok[j] = gid < (long long)per_img * B;
+                const int b = ok[j] ? (int)(gid / per_img) : 0;
+                int Y, X;
+                ring_pixel(ok[j] ? (int)(gid - (long long)b * per_img) : 0, Hs, Ws, Y, X);
+                ok[j] = ok[j] && (((Y + X) & 1) == pass);
+                spp[j] = (Y & 1) * 2 + (X & 1);
+                vv[j] = variant_of(Y, X, Hs, Ws);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const size_t off = (((size_t)b * 3 + c) * Hs + Y) * Ws + X;
+                    gv[j][c] = ui[off] > 0.f ? g[off] : 0.f;
+                }
+                const int ly = Y >> 1, lx = X >> 1;
+#pragma unroll
+                for (int a = 0; a < 7; ++a) {
+                    const int tap = tg + 4 * a;
+                    const int iy = ly + tap / 5 - 2, ix = lx + tap % 5 - 2;
+                    f[j][a] = (a < ntap && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                  ? bf16_to_f32(x[(((size_t)b * H + iy) * W + ix) * 64 + ci]) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!ok[j]) continue;
+                if (vv[j] != cur_v || spp[j] != cur_sp) {
+                    flush();
+                    cur_v = vv[j]; cur_sp = spp[j];
+#pragma unroll
+                    for (int a = 0; a < 7; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[a][c] = 0.f;
+                }
+                if (threadIdx.x < 3) atomicAdd(Gb + (blockIdx.x % REP) * GBSZ + vv[j] * NOUT + threadIdx.x * 4 + spp[j], gv[j][threadIdx.x]);
 #pragma unroll
                 for (int a = 0; a < 7; ++a)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[a][c] = 0.f;
-            }
-            float gv[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const size_t off = (((size_t)b * 3 + c) * Hs + Y) * Ws + X;
-                gv[c] = ui[off] > 0.f ? g[off] : 0.f;
-            }
-            if (threadIdx.x < 3) atomicAdd(Gb + v * NOUT + threadIdx.x * 4 + sp, gv[threadIdx.x]);
-            const int ly = Y >> 1, lx = X >> 1;
-#pragma unroll
-            for (int a = 0; a < 7; ++a) {
-                if (a < ntap) {
-                    const int tap = tg + 4 * a;
-                    const int iy = ly + tap / 5 - 2, ix = lx + tap % 5 - 2;
-                    const float f = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? bf16_to_f32(x[(((size_t)b * H + iy) * W + ix) * 64 + ci]) : 0.f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) acc[a][c] = fmaf(gv[c], f, acc[a][c]);
-                }
+                    for (int c = 0; c < 3; ++c) acc[a][c] = fmaf(gv[j][c], f[j][a], acc[a][c]);
             }
         }
     }
@@ -439,8 +454,9 @@ __global__ __launch_bounds__(256) void bra_chain_dm_kernel(const float* __restri
             const int n = o3 * 4 + si * 2 + sj, t = (oy + 1 + ky) * 5 + (ox + 1 + kx);
             for (int v = 0; v < NV; ++v) {
                 if (dropped(v / 3, dy) || dropped(v % 3, dx)) continue;
-                s += G[(((size_t)v * NOUT + n) * NTAP + t) * 64 + ci];
-                if (ci == 0 && ky == 0 && kx == 0) sb += Gb[v * NOUT + n];
+                for (int rp = 0; rp < REP; ++rp) s += G[(size_t)rp * GSZ + (((size_t)v * NOUT + n) * NTAP + t) * 64 + ci];
+                if (ci == 0 && ky == 0 && kx == 0)
+                    for (int rp = 0; rp < REP; ++rp) sb += Gb[rp * GBSZ + v * NOUT + n];
             }
         }
     }
@@ -517,7 +533,8 @@ extern "C" int tup_bra_compose(const float* wu, const float* bu, const float* w3
 
 // Backward of the composed branch A (r = 2).  g fp32 [B][3][2H][2W] = gradient w.r.t. upscaled_input (before its ReLU mask),
 // ui fp32 [B][3][2H][2W] = upscaled_input (the ReLU mask is ui > 0), feat bf16 [B][H][W][64].
-// Outputs: dfeat bf16 [B][H][W][64] (written), G fp32 [9][12][25][64] and Gb fp32 [9][12] (ACCUMULATED: zero them first),
+// Outputs: dfeat bf16 [B][H][W][64] (written), G fp32 [16 replicas][9][12][25][64] and Gb fp32 [16][9][12] (ACCUMULATED: zero
+// them first; the gradient is the sum over the replicas, taken by tup_bra_chain),
 // g12 bf16 [B][H][W][16] workspace.  H, W >= 6.
 extern "C" int tup_bra_backward(const float* g, const float* ui, const void* feat, const void* wd, const void* wv,
                                 void* g12, void* dfeat, float* G, float* Gb, int B, int H, int W, void* stream)
@@ -544,7 +561,7 @@ extern "C" int tup_bra_backward(const float* g, const float* ui, const void* fea
     bra_wgrad_kernel<<<dim3(persistent_blocks(nt)), dim3(256), WGRAD_LDS, s>>>((const bf16_t*)feat, (const bf16_t*)g12, G, B, H, W, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     const long long nring = (long long)B * (4LL * W + 2LL * (2 * H - 2));
-    bra_wgrad_ring_kernel<<<dim3((unsigned)((nring + 127) / 128)), dim3(256), 0, s>>>(g, ui, (const bf16_t*)feat, G, Gb, B, H, W);
+    bra_wgrad_ring_kernel<<<dim3((unsigned)((nring + RING_RUN - 1) / RING_RUN)), dim3(256), 0, s>>>(g, ui, (const bf16_t*)feat, G, Gb, B, H, W);
     TUP_CHECK_LAUNCH();
     return 0;
 }

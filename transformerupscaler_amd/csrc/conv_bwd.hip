@@ -631,7 +631,9 @@ extern "C" int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float*
     if (r < 1 || r > 6) return (int)hipErrorInvalidValue;
     const int cout = 3 * r * r;
     if (cout * 28 > 12 * 256) return (int)hipErrorInvalidValue;
-    const int th = (r >= 4) ? 2 : (r == 3 ? 4 : 8);
+    // rows per tile: as many as keep four workgroups' LDS tiles on a CU (a tile's staging loops and two barriers are fixed costs:
+    // 8-row tiles at r = 1 left each thread ONE pixel of arithmetic per tile)
+    const int th = (r >= 4) ? 2 : (r == 3 ? 4 : (r == 2 ? 16 : 32));
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + th - 1) / th;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;

@@ -45,7 +45,7 @@ def _opt(t, dtype, shape, name):
 # bias gradients).  One torch.zeros of the whole lot + views replaces 130 fill launches.  The pool is a fresh allocation per
 # backward pass and stays alive as long as any gradient view does, so there is no reuse hazard. ----
 _zero_pool = None          # [tensor, next free offset (floats)]
-_ZERO_POOL_FLOATS = int(os.environ.get("TUP_ZERO_POOL_FLOATS", str(6 * 1024 * 1024)))
+_ZERO_POOL_FLOATS = int(os.environ.get("TUP_ZERO_POOL_FLOATS", str(9 * 1024 * 1024)))
 
 
 def zero_pool_begin(device):
@@ -756,8 +756,8 @@ def bra_backward(g, ui, feat, comp, wu, bu, w3):
     dev = feat.device
     g12 = torch.empty((B, H, W, 16), dtype=BF16, device=dev)
     dfeat = torch.empty((B, H, W, 64), dtype=BF16, device=dev)
-    G = _zeros((9, 12, 25, 64), dev)
-    Gb = _zeros((9, 12), dev)
+    G = _zeros((16, 9, 12, 25, 64), dev)          # 16 replicas against atomic contention, summed by tup_bra_chain
+    Gb = _zeros((16, 9, 12), dev)
     _lib.call("tup_bra_backward", _chk(g, F32, None, "g"), _chk(ui, F32, g.shape, "ui"), _chk(feat, BF16, None, "feat"),
               _chk(comp["wd"], BF16, (13, 64, 32), "wd"), _chk(comp["wv"], BF16, (9, 12, 25, 64), "wv"),
               g12.data_ptr(), dfeat.data_ptr(), G.data_ptr(), Gb.data_ptr(), B, H, W, _stream())

@@ -482,17 +482,39 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_kernel(
     const float* pr = pre ? pre + (size_t)plane * Ho * Wo : nullptr;
     float acc = 0.f;
     const int ya = oy0[y], yn = oyn[y], xa = ox0[x], xn = oxn[x];
-    for (int i = 0; i < yn; ++i) {
-        const int oy = ya + i;
-        const float wyv = yw[oy * KY + (y - ymin[oy])];
-        float h = 0.f;
-        for (int j = 0; j < xn; ++j) {
-            const int ox = xa + j;
-            float gv = go[(size_t)oy * Wo + ox];
-            if (pr) { const float pv = pr[(size_t)oy * Wo + ox]; if (!(pv >= 0.f && pv <= 1.f)) gv = 0.f; }
-            h = fmaf(xw[ox * KX + (x - xmin[ox])], gv, h);
+    if (xn <= 4) {
+        // column weights once per thread, a row's taps requested together (as in resize_aa_kernel)
+        float wx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int ox = min(xa + j, Wo - 1); wx[j] = j < xn ? xw[ox * KX + (x - xmin[ox])] : 0.f; }
+        for (int i = 0; i < yn; ++i) {
+            const int oy = ya + i;
+            const float wyv = yw[oy * KY + (y - ymin[oy])];
+            float gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t o = (size_t)oy * Wo + min(xa + j, Wo - 1);
+                gv[j] = j < xn ? go[o] : 0.f;
+                if (pr) { const float pv = pr[o]; if (!(pv >= 0.f && pv <= 1.f)) gv[j] = 0.f; }
+            }
+            float h = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h = fmaf(wx[j], gv[j], h);
+            acc = fmaf(wyv, h, acc);
         }
-        acc = fmaf(wyv, h, acc);
+    } else {
+        for (int i = 0; i < yn; ++i) {
+            const int oy = ya + i;
+            const float wyv = yw[oy * KY + (y - ymin[oy])];
+            float h = 0.f;
+            for (int j = 0; j < xn; ++j) {
+                const int ox = xa + j;
+                float gv = go[(size_t)oy * Wo + ox];
+                if (pr) { const float pv = pr[(size_t)oy * Wo + ox]; if (!(pv >= 0.f && pv <= 1.f)) gv = 0.f; }
+                h = fmaf(xw[ox * KX + (x - xmin[ox])], gv, h);
+            }
+            acc = fmaf(wyv, h, acc);
+        }
     }
     gin[((size_t)plane * Hi + y) * Wi + x] = acc;
 }

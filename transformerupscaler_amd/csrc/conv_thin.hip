@@ -321,11 +321,29 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(
     const float* src = in + (size_t)plane * Hi * Wi;
     const int y0 = ymin[oy], ny = ysize[oy], x0 = xmin[ox], nx = xsize[ox];
     float acc = 0.f;
-    for (int i = 0; i < ny; ++i) {
-        const float* rowp = src + (size_t)(y0 + i) * Wi + x0;
-        float h = 0.f;
-        for (int j = 0; j < nx; ++j) h = fmaf(xw[ox * KX + j], rowp[j], h);
-        acc = fmaf(yw[oy * KY + i], h, acc);
+    if (nx <= 8) {
+        // the column weights live in registers for all rows and the taps of a row are requested together (the rolled
+        // double loop re-read a weight and paid a load round trip per tap: 317 us for 3 x 4 planes of 1440x2560 -> 1080x1920)
+        float wx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wx[j] = j < nx ? xw[ox * KX + j] : 0.f;
+        for (int i = 0; i < ny; ++i) {
+            const float* rowp = src + (size_t)(y0 + i) * Wi + x0;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = j < nx ? rowp[j] : 0.f;
+            float h = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h = fmaf(wx[j], v[j], h);
+            acc = fmaf(yw[oy * KY + i], h, acc);
+        }
+    } else {
+        for (int i = 0; i < ny; ++i) {
+            const float* rowp = src + (size_t)(y0 + i) * Wi + x0;
+            float h = 0.f;
+            for (int j = 0; j < nx; ++j) h = fmaf(xw[ox * KX + j], rowp[j], h);
+            acc = fmaf(yw[oy * KY + i], h, acc);
+        }
     }
     if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
     out[((size_t)plane * Ho + oy) * Wo + ox] = acc;

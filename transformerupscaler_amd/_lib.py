@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 P = c_void_p
 I = c_int

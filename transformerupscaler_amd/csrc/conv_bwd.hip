@@ -5,6 +5,7 @@
 // (Input gradients of the 64-channel convs reuse the forward implicit-GEMM kernels with
 // transposed / flipped weights: conv3x3_c64.hip, conv_thin.hip.)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -348,10 +349,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(
 // gradients (+ 3 bias sums) in registers for its whole persistent run: 30 LDS reads per 81 FMAs.  (v1 gave each THREAD
 // one (cout, tap) output and looped it over the tile's pixels -- 84 of 256 threads busy at r = 1, two LDS reads per FMA;
 // 0.7 ms per call.)  The per-thread sums are combined through LDS float atomics once at the end.
+// RT / THT > 0: compile-time r and rows per tile -> the tile's operands are fetched into registers one tile AHEAD (all loads of a
+// tile in flight under the previous tile's arithmetic); RT = 0: generic r, staged in place (a load -> LDS-store loop with
+// run-time bounds is not unrolled and pays a global round trip per iteration: 20 us per 1,024-pixel tile, the whole 0.36 ms).
+template <int RT, int THT>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
     const float* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dw, float* __restrict__ dbias,
-    int B, int H, int W, int r, int th, int tilesX, int tilesY)
+    int B, int H, int W, int r_, int th_, int tilesX, int tilesY)
 {
+    const int r = RT > 0 ? RT : r_, th = RT > 0 ? THT : th_;
     extern __shared__ __attribute__((aligned(16))) float fl[];
     const int cout = 3 * r * r, rr = r * r;
     float* x_lds = fl;                               // [3][th+2][HALO_W]
@@ -370,26 +376,90 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
     for (int i = tid; i < rr * 84; i += 256) red[i] = 0.f;
     const int Hr = H * r, Wr = W * r;
     const int ntiles = tilesX * tilesY * B;
+    constexpr int XRm = RT > 0 ? (THT + 2 + 7) / 8 : 1, GRm = RT > 0 ? THT / 8 : 1, COm = RT > 0 ? 3 * RT * RT : 1;
+    float xv[3][XRm][2], gv[COm][GRm];
+    auto fetch_regs = [&](int tile_) {
+        if constexpr (RT > 0) {
+            int t_ = tile_;
+            const int tx_ = t_ % tilesX; t_ /= tilesX;
+            const int ty_ = t_ % tilesY, b_ = t_ / tilesY;
+            const int y0_ = ty_ * THT, x0_ = tx_ * TW;
+            const int lx_ = tid & 31, ly_ = tid >> 5;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* xc = x + ((size_t)b_ * 3 + c) * H * W;
+#pragma unroll
+                for (int k = 0; k < XRm; ++k) {
+                    const int iy = y0_ - 1 + ly_ + 8 * k, ix = x0_ - 1 + lx_;
+                    const bool rowok = iy >= 0 && iy < H && ly_ + 8 * k < THT + 2;
+                    xv[c][k][0] = (rowok && ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f;
+                    xv[c][k][1] = (rowok && lx_ < HALO_W - 32 && ix + 32 < W) ? xc[(size_t)iy * W + ix + 32] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int co = 0; co < COm; ++co) {
+                const int c = co / (RT * RT), sp = co % (RT * RT), si = sp / RT, sj = sp % RT;
+                const float* gc = gpl + ((size_t)b_ * 3 + c) * Hr * Wr;
+#pragma unroll
+                for (int k = 0; k < GRm; ++k) {
+                    const int oy = y0_ + ly_ + 8 * k, ox = x0_ + lx_;
+                    gv[co][k] = (oy < H && ox < W) ? gc[(size_t)(oy * RT + si) * Wr + (ox * RT + sj)] : 0.f;
+                }
+            }
+        }
+    };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
         const int ty = t % tilesY;
         const int b = t / tilesY;
         const int ty0 = ty * th, tx0 = tx * TW;
-        for (int idx = tid; idx < 3 * (th + 2) * HALO_W; idx += 256) {
-            const int c = idx / ((th + 2) * HALO_W), q = idx - c * (th + 2) * HALO_W;
-            const int yy = q / HALO_W, xx = q - yy * HALO_W;
-            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
-            x_lds[idx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((size_t)b * 3 + c) * H + iy) * W + ix] : 0.f;
-        }
-        for (int idx = tid; idx < cout * npix; idx += 256) {
-            const int co = idx / npix, pix = idx - co * npix;
-            const int oy = ty0 + (pix >> 5), ox = tx0 + (pix & 31);
-            const int c = co / rr, s2 = co - c * rr;
-            const int si = s2 / r, sj = s2 - si * r;
-            g_lds[idx] = (oy < H && ox < W) ? gpl[(((size_t)b * 3 + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj)] : 0.f;
+        const int lx = tid & 31, ly = tid >> 5;                       // 8 rows of 32 columns per pass
+        if constexpr (RT > 0) {
+            constexpr int XR = (THT + 2 + 7) / 8, GR = THT / 8, CO = 3 * RT * RT;
+            if (tile == (int)blockIdx.x) fetch_regs(tile);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int k = 0; k < XR; ++k) {
+                    const int yy = ly + 8 * k;
+                    if (yy < THT + 2) {
+                        x_lds[(c * (THT + 2) + yy) * HALO_W + lx] = xv[c][k][0];
+                        if (lx < HALO_W - 32) x_lds[(c * (THT + 2) + yy) * HALO_W + lx + 32] = xv[c][k][1];
+                    }
+                }
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+#pragma unroll
+                for (int k = 0; k < GR; ++k) g_lds[co * npix + (ly + 8 * k) * 32 + lx] = gv[co][k];
+        } else {
+            for (int c = 0; c < 3; ++c) {
+                const float* xc = x + ((size_t)b * 3 + c) * H * W;
+                float* xl = x_lds + c * (th + 2) * HALO_W;
+                for (int yy = ly; yy < th + 2; yy += 8) {
+                    const int iy = ty0 - 1 + yy;
+                    const bool rowok = iy >= 0 && iy < H;
+                    const int ix = tx0 - 1 + lx;
+                    xl[yy * HALO_W + lx] = (rowok && ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f;
+                    if (lx < HALO_W - 32) {
+                        const int ix2 = ix + 32;
+                        xl[yy * HALO_W + lx + 32] = (rowok && ix2 < W) ? xc[(size_t)iy * W + ix2] : 0.f;
+                    }
+                }
+            }
+            for (int c = 0; c < 3; ++c)
+                for (int si = 0; si < r; ++si)
+                    for (int sj = 0; sj < r; ++sj) {
+                        const int co = c * rr + si * r + sj;
+                        const float* gc = gpl + ((size_t)b * 3 + c) * Hr * Wr;
+                        for (int py = ly; py < th; py += 8) {
+                            const int oy = ty0 + py, ox = tx0 + lx;
+                            g_lds[co * npix + py * 32 + lx] = (oy < H && ox < W) ? gc[(size_t)(oy * r + si) * Wr + (ox * r + sj)] : 0.f;
+                        }
+                    }
         }
         __syncthreads();
+        if constexpr (RT > 0) { if (tile + (int)gridDim.x < ntiles) fetch_regs(tile + gridDim.x); }
         if (worker)
             for (int pix = slot; pix < npix; pix += nslot) {
                 const float g0 = g_lds[(0 * rr + ph) * npix + pix], g1 = g_lds[(1 * rr + ph) * npix + pix],
@@ -407,7 +477,25 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
             }
         __syncthreads();
     }
-    if (worker) {
+    if (rr == 1 || rr == 4) {
+        // lanes of one phase are rr apart: butterfly over the wave first, then ONE LDS atomic per wave and value (256 threads
+        // adding to the same 84 LDS words serialised 64-fold per wave: this tail was most of the kernel's 0.39 ms)
+        const int lane = tid & 63;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 28; ++k) {
+                float v = (k < 27) ? acc[c][k < 27 ? k : 0] : bsum[c];
+                if constexpr (RT > 0) {            // compile-time butterfly: the 84 chains overlap instead of serialising
+#pragma unroll
+                    for (int o = 32; o >= RT * RT; o >>= 1) v += __shfl_xor(v, o);
+                } else {
+                    for (int o = 32; o >= rr; o >>= 1) v += __shfl_xor(v, o);
+                }
+                if (lane < rr) atomicAdd(red + ph * 84 + c * 28 + k, v);
+            }
+        }
+    } else if (worker) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
 #pragma unroll
@@ -660,8 +748,11 @@ extern "C" int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float*
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const size_t lds = ((size_t)3 * (th + 2) * HALO_W + (size_t)cout * th * 32 + (size_t)r * r * 84) * sizeof(float);
-    conv3x3_wgrad_planar_kernel<<<dim3(persistent_grid(nt, 4)), dim3(256), lds, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
+    const dim3 grid(persistent_grid(nt, 4));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (r == 1) conv3x3_wgrad_planar_kernel<1, 32><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
+    else if (r == 2) conv3x3_wgrad_planar_kernel<2, 16><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
+    else conv3x3_wgrad_planar_kernel<0, 0><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     return 0;
 }

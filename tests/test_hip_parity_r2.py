@@ -378,3 +378,30 @@ def test_input_gradient_matches_oracle(det_sd):
     rel = (xg.grad.cpu().double() - xo.grad.double()).norm().item() / xo.grad.double().norm().item()
     print("input-gradient relative L2", rel)
     assert rel <= 0.10, rel
+
+
+@pytest.mark.parametrize("name", ["FastTransformer", "ResidualTransformer", "WindowTransformer"])
+def test_train_mode_without_grad_applies_dropout(name, det_sd):
+    """ADVICE r1: the reference's nn.Dropout layers are active whenever the module is in .train(), with or without gradients;
+    all three plugins now behave the same: a no_grad forward in .train() equals the same-seed training forward (and differs
+    from .eval())."""
+    from transformerupscaler_amd import weights as Wt
+    m = importlib.import_module(f"models.{name}.model").TransformerModel()
+    sd = {"FastTransformer": lambda: det_sd, "ResidualTransformer": lambda: Wt.rt_deterministic_state_dict(0),
+          "WindowTransformer": lambda: Wt.wt_deterministic_state_dict(0)}[name]()
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    shape = (1, 3, 720, 1280) if name == "ResidualTransformer" else (1, 3, 64, 96)
+    kw = dict(res_out=(1080, 1920)) if name == "ResidualTransformer" else dict(upscale_factor=2)
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(4)).cuda()
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x, **kw)
+    m.train()
+    calls = m._dropout_calls
+    with torch.no_grad():
+        y_ng = m(x, **kw)
+    m._dropout_calls = calls
+    y_g = m(x, **kw)                                   # same seed through the autograd path
+    assert torch.equal(y_ng, y_g.detach())
+    assert (y_ng - y_eval).abs().max().item() > 1e-5   # dropout did something

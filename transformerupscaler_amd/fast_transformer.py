@@ -194,6 +194,14 @@ class TransformerModel(nn.Module):
         if needs_grad:
             from .autograd import fast_transformer_function   # training path (forward + hand-written backward)
             out = fast_transformer_function(self, x, scale, res_out, require_ratio)
+        elif self.training and self.dropout_p > 0.0:
+            # .train() without gradients (e.g. a validation pass that forgot .eval()): the reference's nn.Dropout layers are
+            # active whenever the module is in training mode, so run the training forward (dropout in its kernels) and
+            # drop what it saved
+            from .autograd import forward_train
+            pk, frags_t, _ = self.packed(scale, backward=True)
+            drop_p, seed = self._next_dropout()
+            out, _ = forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p, seed)
         else:
             pk, frags = self.packed(scale)
             out = engine.forward(pk, frags, x, scale, res_out, require_ratio)

@@ -98,8 +98,11 @@ class TransformerModel(nn.Module):
             from .autograd_rt import residual_transformer_function
             out = residual_transformer_function(self, x, tuple(int(v) for v in res_out))
             return out.to(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else out
-        if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("ResidualTransformer: .train() forward without gradients is not built; use .eval() under no_grad")
+        if self.training and self.dropout_p > 0.0:       # dropout is active in .train() with or without gradients, as in the reference
+            from .autograd_rt import forward_train
+            drop_p, seed = self._next_dropout()
+            out, _ = forward_train(self.packed(backward=True), x, tuple(int(v) for v in res_out), drop_p, seed)
+            return out.to(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else out
         pk = self.packed()
         x = x.contiguous().float()
         feat = ops.conv_c64(ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True), pk["conv2.w"], pk["conv2.b"], 1, relu=True)

@@ -82,8 +82,12 @@ class TransformerModel(nn.Module):
             from .autograd_wt import window_transformer_function
             out = window_transformer_function(self, x, tuple(int(v) for v in res_out))
             return out.to(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else out
-        if self.training and self.dropout_p > 0.0:
-            raise NotImplementedError("WindowTransformer: .train() forward without gradients is not built; use .eval() under no_grad")
+        if self.training and self.dropout_p > 0.0:       # dropout is active in .train() with or without gradients, as in the reference
+            from .autograd_wt import forward_train
+            pk, frags_t, _ = self.packed(backward=True)
+            drop_p, seed = self._next_dropout()
+            out, _ = forward_train(pk, frags_t, self.num_heads, x, tuple(int(v) for v in res_out), drop_p, seed)
+            return out.to(torch.get_autocast_gpu_dtype()) if torch.is_autocast_enabled() else out
         pk, frags = self.packed()
         x = x.contiguous().float()
         feat = ops.conv_c64(ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True), pk["conv2.w"], pk["conv2.b"], 1, relu=True)

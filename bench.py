@@ -367,7 +367,8 @@ def main():
 
     conv_ms = sum(s.elapsed_time(e) for s, e in events) / max(len(events), 1)                  # one conv2 launch
     blocks_ms = sum(s.elapsed_time(e) for s, e in block_events) / max(len(block_events), 1)     # the 6 whole-block launches of a forward
-    n_block_launch = 6
+    from transformerupscaler_amd import engine as _engine
+    n_block_launch = 1 if _engine.blocks_in_one_launch else 6
     blk_ms = blocks_ms / n_block_launch
     attn_tf = ATTN_SET_FLOP_PER_IMAGE * args.batch / (blocks_ms * 1e-3) / 1e12 if blocks_ms > 0 else 0.0
     conv_tf = CONV64_FLOP_PER_IMAGE * args.batch / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
@@ -377,12 +378,14 @@ def main():
     if args.batch != 8:
         blk_traffic = conv_traffic = None
     roof_block = {"bound": "mfma",
-                  "kernel": "fused_qkv_attn_kernel<true,true> (one whole WindowTransformerBlock per launch: norm1 + qkv + window attention + proj + "
-                            "residual + norm2 + fc1 + GELU + fc2 + residual; 6 launches per forward)",
+                  "kernel": "fused_qkv_attn_kernel<true,true> (whole WindowTransformerBlocks: norm1 + qkv + window attention + proj + residual + "
+                            "norm2 + fc1 + GELU + fc2 + residual; " + ("the 6 blocks of a forward in ONE launch)" if n_block_launch == 1
+                                                                       else "one block per launch, 6 launches per forward)"),
+                  "blocks_per_launch": 6 // n_block_launch, "ms_per_block": blocks_ms / 6,
                   "achieved": attn_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / MFMA_BF16_PEAK_TFLOPS,
                   "traffic": blk_traffic, "traffic_source": blk_src,
                   "algorithmic_flop_per_launch": ATTN_SET_FLOP_PER_IMAGE * args.batch / n_block_launch,
-                  "algorithmic_bytes": nwin * 64 * 192 * 4 * 2,       # the fp32 residual stream read once + written once
+                  "algorithmic_bytes": nwin * 64 * 192 * 4 * 2,       # per launch: the fp32 residual stream read once + written once
                   "ms_per_launch": blk_ms, "total_ms_per_forward": blocks_ms, "launches_timed": len(block_events) * n_block_launch,
                   "note": "algorithmic FLOPs = SURVEY 8(d)'s window-attention GEMM set (qkv, QK^T, PV, proj, fc1, fc2 = 86.1 GF per image); "
                           "LayerNorm / softmax / GELU run inside the same launches and are not counted; north_star target frac >= 0.40"}

@@ -360,6 +360,13 @@ int tup_resize_u8_rows(const void* src, void* dst, const int* xmin, const int* x
 int tup_resize_u8_cols(const void* src, void* dst_u8, float* dst_f32, const int* ymin, const int* ysize, const int* k,
                        int ksize, int B, int H, int W, int Ho, int swap_rb, void* stream);
 
+/* nblk (<= 8) consecutive WindowTransformerBlocks in ONE launch (the loop `for block in self.window_blocks`, model.py:288-289), with
+ * the default kernel's geometry (two waves per window, two workgroups per CU): between blocks the residual stream passes through
+ * memory as each wave's own stores followed by its own loads (L2), so the launch boundaries and their chip-wide load / store bursts
+ * disappear.  x fp32 [64*nwin][192] in place; table: HOST array [nblk][13] of device pointers, per block the arguments of
+ * tup_fused_block_fwd after x in that order and packing. */
+int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
+
 /* nblk consecutive WindowTransformerBlocks in ONE launch with ONE WAVE PER WINDOW (64 tokens = four MFMA token tiles per wave,
  * one 256-thread workgroup per CU with the whole register file): replaces the loop `for block in self.window_blocks`,
  * model.py:288-289, with WindowTransformerBlock.forward :153-172 and WindowAttention.forward :104-133 inside.  K and V never

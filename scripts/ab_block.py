@@ -1,0 +1,45 @@
+"""A/B of builds of the whole-block kernel in ONE process on the MI355X box (interleaved rounds, same GPU, same data):
+    python scripts/ab_block.py name=path/to/lib.so [name=...]      (scripts/_ab_build.sh makes the libraries)
+Per library: 6 launches of tup_fused_block_fwd, and tup_fused_blocks32_fwd (6 blocks, one launch) where exported."""
+import ctypes, os, sys
+import torch
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from transformerupscaler_amd import ops
+import test_hip_kernels as T
+
+nwin, rounds = 1920, 15
+libs = dict(a.split("=") for a in sys.argv[1:])
+raw, args = T._block_operands("cuda", nwin)
+x0 = raw["x"].to("cuda")
+arr, nblk, keep = ops.block_table([tuple(args)] * 6)
+P, I = ctypes.c_void_p, ctypes.c_int
+runs = {}
+for name, path in libs.items():
+    L = ctypes.CDLL(os.path.join(root, path))
+    L.tup_fused_block_fwd.argtypes = [P] * 14 + [I, P]
+    ptrs = [a.data_ptr() for a in args]
+    runs[name + "/6 launches"] = (lambda x, L=L, ptrs=ptrs: [L.tup_fused_block_fwd(x.data_ptr(), *ptrs, nwin, None) for _ in range(6)])
+    if hasattr(L, "tup_fused_blocks32_fwd"):
+        L.tup_fused_blocks32_fwd.argtypes = [P, P, I, I, P]
+        runs[name + "/1 launch"] = (lambda x, L=L: L.tup_fused_blocks32_fwd(x.data_ptr(), arr, 6, nwin, None))
+x = x0.clone()
+ref = None
+for k, f in runs.items():
+    for _ in range(2):
+        x.copy_(x0); f(x)
+    torch.cuda.synchronize()
+    ref = x.clone() if ref is None else ref
+    print(k, "max |diff| vs first variant", (x - ref).abs().max().item())
+times = {k: [] for k in runs}
+st = torch.cuda.current_stream()
+assert st.cuda_stream == 0, "the libraries are launched on the null stream"
+for r in range(rounds):
+    for k, f in runs.items():
+        x.copy_(x0)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); f(x); e.record(); torch.cuda.synchronize()
+        times[k].append(s.elapsed_time(e) / 6 * 1e3)
+for k, t in times.items():
+    t = sorted(t)
+    print(f"{k}: median {t[len(t) // 2]:.1f} us  min {t[0]:.1f} us per block")

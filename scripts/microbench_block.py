@@ -12,20 +12,22 @@ dev = "cuda"
 import test_hip_kernels as T
 raw, args = T._block_operands(dev, nwin)
 x0 = raw["x"].to(dev)
-variants = {"block32": 32, "block64": 64, "blocks64x6": 0}
+variants = {"block32": 32, "blocks32x6": -1, "block64": 64, "blocks64x6": 0}
 table6 = ops.block_table([tuple(args)] * 6)
 xs = {k: x0.clone() for k in variants}
 times = {k: [] for k in variants}
 for k, tpw in variants.items():                       # warm-up
     for _ in range(3):
-        ops.fused_block(xs[k], *args, tokens_per_wave=tpw or 64)
+        ops.fused_block(xs[k], *args, tokens_per_wave=tpw if tpw > 0 else 32)
 torch.cuda.synchronize()
 for r in range(rounds):
     for k, tpw in variants.items():
         xs[k].copy_(x0)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        if tpw == 0:
+        if tpw == -1:
+            ops.fused_blocks32(xs[k], table6)
+        elif tpw == 0:
             ops.fused_blocks64(xs[k], table6)          # the 6 blocks of a forward in one launch
         else:
             for _ in range(6):                            # ... as 6 launches

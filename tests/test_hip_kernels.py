@@ -602,6 +602,8 @@ def test_blocks64_six_in_one_launch_equals_six_launches(dev):
         ops.fused_block(ref, *a, tokens_per_wave=64)
     assert torch.isfinite(one).all()
     assert torch.equal(one, ref)
+    one32 = ops.fused_blocks32(x.clone(), ops.block_table([tuple(a) for a in seq]))
+    assert torch.equal(one32, ref)                    # the default kernel in one launch: the same bits again
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 8, 32), (1, 13, 37), (2, 24, 70), (1, 6, 6)])

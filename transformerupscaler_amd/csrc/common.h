@@ -73,6 +73,14 @@ TUP_DEVICE int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >
 // (hipcc folds an arithmetic combination of the swap's two results to its first operand when both inputs are the same value --
 // it drops the cross-lane exchange -- so the second result passes through an empty asm; v_max in asm also avoids the
 // canonicalising v_max x, x pair hipcc puts in front of fmaxf)
+// The lane id out of thin air (two VALU ops, no input register): inside a long loop per-lane addresses rebuilt from it cost a few
+// instructions, where the hoisted originals get spilled by hipcc and come back through scratch_load + s_waitcnt vmcnt(0) -- a
+// wait that also drains every LDS-DMA in flight.  volatile: not hoisted, not merged.
+TUP_DEVICE int lane_id_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 TUP_DEVICE uint32_t opaque_copy(uint32_t u) { asm volatile("" : "+v"(u)); return u; }
 TUP_DEVICE float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 TUP_DEVICE float rows_max(float v) {

@@ -15,6 +15,7 @@
 // Every LDS access inside the head loop is inline asm: a compiler-visible LDS access behind an outstanding LDS-DMA makes
 // hipcc wait vmcnt(0); barriers are raw s_barrier with counted waits for the same reason.
 #include "common.h"
+#include <string.h>
 #include <stdlib.h>
 
 namespace {
@@ -57,7 +58,18 @@ struct MlpArgs {
     const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2;
 };
 constexpr int HID = 768;
-constexpr int M_W2_OFF = 2 * FW_BYTES, M_B1_OFF = 3 * FW_BYTES, FB_LDS = M_B1_OFF + HID * 4;       // 76,800 B
+// parameters of one WindowTransformerBlock; the table is a kernel argument BY VALUE (pointer fields of a kernel argument are
+// global pointers to hipcc; pointers read from memory would be generic and every load through them a flat_load)
+struct BlockPtrs {
+    const float* gamma1; const float* beta1; const bf16_t* wh; const float* bh; const float* bias_frag;
+    const bf16_t* wproj; const float* bproj; MlpArgs ma;
+};
+constexpr int MAX_BLK = 8;
+struct BlockTable { BlockPtrs b[MAX_BLK]; };
+// ... + the four per-channel vectors of the block's second half (b_proj, gamma2, beta2, b2: [4][192] fp32), staged with the biases:
+// read from global where they are used they cost ~45 dependent round trips behind the weight DMA queue (17k cycles per block)
+constexpr int M_W2_OFF = 2 * FW_BYTES, M_B1_OFF = 3 * FW_BYTES, M_VEC_OFF = M_B1_OFF + HID * 4;
+constexpr int FB_LDS = M_VEC_OFF + 4 * DIM * 4;                                                      // 79,872 B, two per CU
 
 // Diagnostic build only (STAMPS = true, TUP_B32_STAMPS=1): s_memtime at phase boundaries, summed per phase kind, for 8 recorded
 // workgroups; the values leave through a buffer nothing else reads.
@@ -74,28 +86,58 @@ enum { P_LN1 = 0, P_SYNC0, P_QKV, P_HBAR, P_ATT, P_PROJ, P_LN2, P_MTOP, P_FC1, P
 
 template <bool PROJ, bool MLP = false, bool STAMPS = false>
 __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
-    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const bf16_t* __restrict__ wh, const float* __restrict__ bh, const float* __restrict__ bias_frag,
-    bf16_t* __restrict__ out, int nwin, const bf16_t* __restrict__ wproj, const float* __restrict__ bproj, float* __restrict__ xio,
-    const MlpArgs ma)
+    const float* __restrict__ x_in, bf16_t* __restrict__ out, int nwin, float* __restrict__ xio, const BlockTable tbl, int nblk)
 {
+    // in place (PROJ): every access to the residual stream goes through xio -- with the block loop below a load through a second
+    // __restrict__ pointer could be moved above the previous block's stores
+    const float* x = PROJ ? xio : x_in;
     static_assert(!MLP || PROJ, "the MLP half follows the proj");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long ph[NPH32] = {}, tprev = 0, tstart = 0;
+    if constexpr (STAMPS) tprev = tstart = stamp_now32();
+#define B32_STAMP(K) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now32(); ph[K] += t_ - tprev; tprev = t_; } } while (0)
+
+    // nblk consecutive blocks in one launch (whole-block variant): a window never meets another window (same partition in every
+    // block, model.py:283-289), so this workgroup carries its two windows through all of them; between blocks x passes through
+    // memory as the waves' own stores followed by their own loads (served by L2), the chip-wide load / store bursts of a launch
+    // boundary and the boundary itself disappear
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+    // the thread's coordinates are recomputed per block from an opaque copy of threadIdx: as loop invariants hipcc hoists the
+    // dozens of per-thread addresses derived from them out of the loop, spills them, and reloads them from scratch inside the
+    // head loop -- scratch loads count on vmcnt, which the counted waits below rely on (LDS-DMA ordering)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    __builtin_assume(tid >= 0 && tid < 256);
+    const int lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, pl = lane & 15;
     const int wi = wave >> 1, hf = wave & 1;
     const int win = blockIdx.x * 2 + wi;
     const bool active = win < nwin;
     const int row0 = (active ? win : nwin - 1) * 64 + 32 * hf;          // first of this wave's 32 token rows
-    unsigned long long ph[NPH32] = {}, tprev = 0, tstart = 0;
-    if constexpr (STAMPS) tprev = tstart = stamp_now32();
-#define B32_STAMP(K) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now32(); ph[K] += t_ - tprev; tprev = t_; } } while (0)
+    const BlockPtrs& bp = tbl.b[blk];
+    const float* __restrict__ gamma = bp.gamma1; const float* __restrict__ beta = bp.beta1;
+    const bf16_t* __restrict__ wh = bp.wh; const float* __restrict__ bh = bp.bh; const float* __restrict__ bias_frag = bp.bias_frag;
+    const bf16_t* __restrict__ wproj = bp.wproj; const float* __restrict__ bproj = bp.bproj;
+    const MlpArgs ma = bp.ma;
+    if (blk) __syncthreads();          // everyone is done with the previous block's LDS (weight slots, W2 chunk, biases)
 
     float* qb = reinterpret_cast<float*>(smem + QB_OFF);
-    for (int i = tid; i < HEADS * 48; i += 256) qb[i] = bh[i];
-    if constexpr (MLP) {           // mlp.0's bias: behind everything the attention half uses, staged before any DMA is in flight
-        float* b1s = reinterpret_cast<float*>(smem + M_B1_OFF);
-        for (int i = tid; i < HID / 4; i += 256) reinterpret_cast<f32x4*>(b1s)[i] = reinterpret_cast<const f32x4*>(ma.b1)[i];
+    {   // fixed trip counts (tid is opaque to the compiler here): all loads first, then the stores
+        static_assert(HEADS * 48 == 576 && HID / 4 <= 256, "staging below assumes 576 biases and <= 256 float4 of b1");
+        const float q0 = bh[tid], q1 = bh[256 + tid], q2 = bh[512 + (tid & 63)];
+        f32x4 b1v = {};
+        if constexpr (MLP) b1v = reinterpret_cast<const f32x4*>(ma.b1)[tid < HID / 4 ? tid : 0];
+        qb[tid] = q0; qb[256 + tid] = q1;
+        if (tid < 64) qb[512 + tid] = q2;
+        if constexpr (MLP) {       // mlp.0's bias: behind everything the attention half uses, staged before any DMA is in flight
+            if (tid < HID / 4) reinterpret_cast<f32x4*>(smem + M_B1_OFF)[tid] = b1v;
+            if (tid < DIM) {
+                const float c0 = bproj[tid], c1 = ma.gamma2[tid], c2 = ma.beta2[tid], c3 = ma.b2[tid];
+                float* vec = reinterpret_cast<float*>(smem + M_VEC_OFF);
+                vec[tid] = c0; vec[DIM + tid] = c1; vec[2 * DIM + tid] = c2; vec[3 * DIM + tid] = c3;
+            }
+        }
     }
 
     // head h's weight slot by DMA: slot s = u*256 + tid -> k-tile u >> 1, row (u & 1)*32 + (tid >> 3), logical chunk
@@ -113,46 +155,60 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     dma_w(1, 1);
 
     // ---- LayerNorm1 straight into B fragments: token 16tg+pl, channels 32*st + 8g .. +8 ----
+    // all 48 loads (the wave's x rows, gamma, beta) stand together in program order, ahead of the arithmetic: written per row as
+    // load-then-use, hipcc under register pressure emits one global round trip per pair of loads
     bf16x8 tf[2][6];
+    {
+        f32x4 v[2][6][2], gm[6][2], bt[6][2];
 #pragma unroll
-    for (int tg = 0; tg < 2; ++tg) {
-        const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + 8 * g;
-        f32x4 v[6][2];
-        float sum = 0.f;
+        for (int tg = 0; tg < 2; ++tg) {
+            const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + 8 * g;
 #pragma unroll
-        for (int st = 0; st < 6; ++st) {
-            v[st][0] = *reinterpret_cast<const f32x4*>(xr + 32 * st);
-            v[st][1] = *reinterpret_cast<const f32x4*>(xr + 32 * st + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) sum += v[st][0][e] + v[st][1][e];
+            for (int st = 0; st < 6; ++st) {
+                v[tg][st][0] = *reinterpret_cast<const f32x4*>(xr + 32 * st);
+                v[tg][st][1] = *reinterpret_cast<const f32x4*>(xr + 32 * st + 4);
+            }
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / DIM);
-        float ss = 0.f;
 #pragma unroll
         for (int st = 0; st < 6; ++st)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[st][hh][e] - mean; ss += d * d; }
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        const float rstd = rsqrtf(ss * (1.0f / DIM) + 1e-5f);
-#pragma unroll
-        for (int st = 0; st < 6; ++st) {
-            uint32_t pk[4];
-#pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 32 * st + 8 * g + 4 * hh);
-                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 32 * st + 8 * g + 4 * hh);
-                float o4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (v[st][hh][e] - mean) * rstd * gm[e] + bt[e];
-                pk[2 * hh] = pack_bf16x2(o4[0], o4[1]);
-                pk[2 * hh + 1] = pack_bf16x2(o4[2], o4[3]);
+                gm[st][hh] = *reinterpret_cast<const f32x4*>(gamma + 32 * st + 8 * g + 4 * hh);
+                bt[st][hh] = *reinterpret_cast<const f32x4*>(beta + 32 * st + 8 * g + 4 * hh);
             }
-            tf[tg][st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            float sum = 0.f;
+#pragma unroll
+            for (int st = 0; st < 6; ++st)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += v[tg][st][0][e] + v[tg][st][1][e];
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float mean = sum * (1.0f / DIM);
+            float ss = 0.f;
+#pragma unroll
+            for (int st = 0; st < 6; ++st)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = v[tg][st][hh][e] - mean; ss += d * d; }
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            const float rstd = rsqrtf(ss * (1.0f / DIM) + 1e-5f);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (v[tg][st][hh][e] - mean) * rstd * gm[st][hh][e] + bt[st][hh][e];
+                    pk[2 * hh] = pack_bf16x2(o4[0], o4[1]);
+                    pk[2 * hh + 1] = pack_bf16x2(o4[2], o4[3]);
+                }
+                tf[tg][st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+            }
         }
     }
 
@@ -408,15 +464,31 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         } else {
             // ---- second half of the block.  acc2 <- the new residual stream x + proj + b_proj (inactive waves carry a
             // copy of the last window and take part in every barrier; only their final store is skipped) ----
+            // per-channel vector k (0 b_proj, 1 gamma2, 2 beta2, 3 b2) at this lane's channels of accumulator n
+            const uint32_t vec_addr = sbase + (uint32_t)(M_VEC_OFF + g * 64);
+            auto vec4 = [&](int k, int n) {
+                return __builtin_bit_cast(f32x4, lds_read_b128_asm_off(vec_addr, k * (DIM * 4) + ((n >> 2) * 64 + (n & 3) * 4) * 4));
+            };
+            {
+                f32x4 rv[2][12];                // the residual stream: all 24 loads in flight before the first use
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
-                const float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+                for (int tg = 0; tg < 2; ++tg) {
+                    const float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
-                for (int n = 0; n < 12; ++n) {
-                    const int col = (n >> 2) * 64 + g * 16 + (n & 3) * 4;
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(xr + col);
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bproj + col);
-                    acc2[tg][n] = (acc2[tg][n] + bv) + rv;
+                    for (int n = 0; n < 12; ++n) rv[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    f32x4 bv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bv[i] = vec4(0, 4 * q + i);
+                    lds_wait<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][4 * q + i] = (acc2[tg][4 * q + i] + bv[i]) + rv[tg][4 * q + i];
                 }
             }
             // LayerNorm2 from the accumulators: this lane holds 48 of its token's 192 channels, the other three lane
@@ -444,12 +516,17 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                 for (int st = 0; st < 6; ++st) {
                     uint32_t pk[4];
+                    f32x4 cv[2][3];            // gamma2, beta2, b2 at channels 64*(st>>1) + 16g + 8*(st&1) + 4hh .. +4 (accumulator 2st+hh)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) cv[hh][k] = vec4(1 + k, 2 * st + hh);
+                    lds_wait<0>();
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
-                        const int c = 64 * (st >> 1) + 16 * g + 8 * (st & 1) + 4 * hh;
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(ma.gamma2 + c);
-                        const f32x4 bt = *reinterpret_cast<const f32x4*>(ma.beta2 + c);
-                        const f32x4 b2v = *reinterpret_cast<const f32x4*>(ma.b2 + c);
+                        const f32x4 gm = cv[hh][0], bt = cv[hh][1], b2v = cv[hh][2];
                         const f32x4 v = acc2[tg][2 * st + hh];
                         float o4[4];
 #pragma unroll
@@ -464,9 +541,13 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 
             B32_STAMP(P_LN2);
             // ---- the chunk loop of fused_mlp_v2_kernel (fused_blocks.hip); W1 chunk j lives in slot (j + 1) & 1 ----
-            const uint32_t w2_off0 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g)), w2_off1 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g + 1));
-            const uint32_t b1_base = sbase + M_B1_OFF + (uint32_t)(g * 64);
             for (int j = 0; j < HID / 64; ++j) {
+                // this lane's LDS addresses, rebuilt per chunk from a fresh lane id (see lane_id_fresh: hoisted, they are spilled
+                // and their reload waits for the W2 DMA issued just above it)
+                const int lf = lane_id_fresh(), g = lf >> 4, pl = lf & 15;
+                const uint32_t w_off = (uint32_t)swz128(pl, g);
+                const uint32_t w2_off0 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g)), w2_off1 = (uint32_t)(M_W2_OFF + swz128(pl, 2 * g + 1));
+                const uint32_t b1_base = sbase + M_B1_OFF + (uint32_t)(g * 64);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of W1 chunk j have landed
                 __syncthreads();                                       // everyone's have; everyone is done with chunk j-1 / the proj
                 dma_w2(j);
@@ -569,13 +650,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                     B32_STAMP(P_FC2);
                 }
             }
-            if (!active) return;
+            if (active) {
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
-                float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+                for (int tg = 0; tg < 2; ++tg) {
+                    float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
-                for (int n = 0; n < 12; ++n)
-                    *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
+                    for (int n = 0; n < 12; ++n)
+                        *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
+                }
             }
             if constexpr (STAMPS) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -583,15 +665,41 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 ph[P_TOTAL] = tprev - tstart;
                 const int b = blockIdx.x;
                 const int rec = b < 4 ? b : (b >= 600 && b < 604 ? 4 + b - 600 : -1);
-                if (rec >= 0 && lane == 0)
+                if (rec >= 0 && lane == 0 && blk == nblk - 1)
 #pragma unroll
                     for (int k = 0; k < NPH32; ++k) tup_b32_stamps[rec][wave][k] = ph[k];
             }
         }
     }
+    }   // blk
 #undef B32_STAMP
 }
 
+}  // namespace
+
+namespace {
+BlockTable one_block(const float* g1, const float* b1n, const void* wh, const float* bh, const float* bias_frag, const void* wproj,
+                     const float* bproj, const MlpArgs& ma)
+{
+    BlockTable t{};
+    t.b[0] = BlockPtrs{g1, b1n, (const bf16_t*)wh, bh, bias_frag, (const bf16_t*)wproj, bproj, ma};
+    return t;
+}
+int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* stream)
+{
+    static const bool stamps = getenv("TUP_B32_STAMPS") != nullptr;          // diagnostic build (timing shares only)
+    const dim3 grid((nwin + 1) / 2);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stamps) {
+        TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, true>), FB_LDS);
+        fused_qkv_attn_kernel<true, true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
+    } else {
+        TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
+        fused_qkv_attn_kernel<true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
+    }
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
 }  // namespace
 
 // att bf16 [M][192] = attention core of qkv(LayerNorm(x)) per 8x8 window (M = 64 * nwin rows in window order):
@@ -603,7 +711,7 @@ extern "C" int tup_fused_qkv_attn_fwd(const float* x, const float* gamma, const 
     if (nwin <= 0) return 0;
     TUP_SET_DYN_LDS((fused_qkv_attn_kernel<false>), FA_LDS);
     fused_qkv_attn_kernel<false><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, (bf16_t*)out, nwin, nullptr, nullptr, nullptr, MlpArgs{});
+        x, (bf16_t*)out, nwin, nullptr, one_block(gamma, beta, wh, bh, bias_frag, nullptr, nullptr, MlpArgs{}), 1);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -616,7 +724,7 @@ extern "C" int tup_fused_attn_block_fwd(float* x, const float* gamma, const floa
     if (nwin <= 0) return 0;
     TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true>), FA_LDS);
     fused_qkv_attn_kernel<true><<<dim3((nwin + 1) / 2), dim3(256), FA_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma, beta, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, MlpArgs{});
+        x, nullptr, nwin, x, one_block(gamma, beta, wh, bh, bias_frag, wproj, bproj, MlpArgs{}), 1);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -630,19 +738,20 @@ extern "C" int tup_fused_block_fwd(float* x, const float* gamma1, const float* b
 {
     if (nwin <= 0) return 0;
     const MlpArgs ma{gamma2, beta2, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
-    static const bool stamps = getenv("TUP_B32_STAMPS") != nullptr;          // diagnostic build (timing shares only)
-    if (stamps) {
-        TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, true>), FB_LDS);
-        fused_qkv_attn_kernel<true, true, true><<<dim3((nwin + 1) / 2), dim3(256), FB_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-            x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, ma);
-        TUP_CHECK_LAUNCH();
-        return 0;
-    }
-    TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
-    fused_qkv_attn_kernel<true, true><<<dim3((nwin + 1) / 2), dim3(256), FB_LDS, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, gamma1, beta1, (const bf16_t*)wh, bh, bias_frag, nullptr, nwin, (const bf16_t*)wproj, bproj, x, ma);
-    TUP_CHECK_LAUNCH();
-    return 0;
+    return launch_blocks32(x, one_block(gamma1, beta1, wh, bh, bias_frag, wproj, bproj, ma), 1, nwin, stream);
+}
+
+// nblk (<= 8) consecutive WindowTransformerBlocks, in place, in ONE launch (the loop of model.py:288-289), two waves per window.
+// table: HOST array [nblk][13] of device pointers in the argument order of tup_fused_block_fwd after x
+// (gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2), same packing.
+extern "C" int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream)
+{
+    if (nwin <= 0 || nblk <= 0) return 0;
+    if (nblk > MAX_BLK || table == nullptr) return (int)hipErrorInvalidValue;
+    static_assert(sizeof(BlockPtrs) == 13 * sizeof(void*), "one table row = 13 pointers");
+    BlockTable t{};
+    memcpy(&t, table, (size_t)nblk * sizeof(BlockPtrs));
+    return launch_blocks32(x, t, nblk, nwin, stream);
 }
 
 // Timing experiments only: per-phase cycle sums of the last TUP_B32_STAMPS=1 launch, [8 workgroups][4 waves][16 phases].

@@ -47,18 +47,19 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
     return (int(res_out[0]), int(res_out[1])), int(upscale_factor)
 
 
+blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 
 
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
-    if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and ops.block_tokens_per_wave == 64:
-        # all six blocks in ONE launch, one wave per window (csrc/fused_block64.hip)
+    if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and blocks_in_one_launch:
+        # all six blocks in ONE launch (csrc/fused_attn.hip, or fused_block64.hip with one wave per window)
         table = ops.block_table([(pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
                                   pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
                                   pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)])
-        return ops.fused_blocks64(x, table)
+        return ops.fused_blocks64(x, table) if ops.block_tokens_per_wave == 64 else ops.fused_blocks32(x, table)
     for i in range(BLOCKS):
         qkv = None
         if fuse_blocks and fuse_attention >= 3 and capture is None and f"b{i}.proj.wpp" in pk:

@@ -291,6 +291,15 @@ def block_table(blocks):
     return ((ctypes.c_void_p * len(ptrs))(*ptrs), len(blocks), [list(b) for b in blocks])
 
 
+def fused_blocks32(x, table):
+    """In place: the table's consecutive WindowTransformerBlocks in one launch, two waves per window (the default kernel)."""
+    M = x.shape[0]
+    assert M % 64 == 0
+    arr, nblk, _keep = table
+    _lib.call("tup_fused_blocks32_fwd", _chk(x, F32, (M, 192), "x"), arr, nblk, M // 64, _stream())
+    return x
+
+
 def fused_blocks64(x, table):
     """In place: the table's consecutive WindowTransformerBlocks in one launch, one wave per window (inference)."""
     M = x.shape[0]

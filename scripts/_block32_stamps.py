@@ -9,8 +9,13 @@ import test_hip_kernels as T
 nwin = 1920
 raw, args = T._block_operands("cuda", nwin)
 x = raw["x"].cuda()
+six = len(sys.argv) > 1 and sys.argv[1] == "6"            # the last of six blocks in one launch instead of a single block
+table6 = ops.block_table([tuple(args)] * 6)
 for _ in range(3):
-    ops.fused_block(x.clone(), *args, tokens_per_wave=32)
+    if six:
+        ops.fused_blocks32(x.clone(), table6)
+    else:
+        ops.fused_block(x.clone(), *args, tokens_per_wave=32)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * (8 * 4 * 16))()

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     __builtin_assume(tid >= 0 && tid < 256);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: DMA targets, window, row0, hf are SALU
     const int g = lane >> 4, pl = lane & 15;
     const int wi = wave >> 1, hf = wave & 1;
     const int win = blockIdx.x * 2 + wi;
@@ -553,7 +553,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 dma_w2(j);
                 const bool more = j + 1 < HID / 64;
                 __builtin_amdgcn_sched_barrier(0);
+                // every LDS read below = one of five per-chunk base registers + an immediate offset
                 const uint32_t wb1 = sbase + (uint32_t)(((j + 1) & 1) * FW_BYTES);
+                const uint32_t w1a0 = wb1 + w_off, w1a1 = wb1 + (w_off ^ 64u);
+                const uint32_t w2a0 = sbase + w2_off0, w2a1 = sbase + w2_off1, b1j = b1_base + (uint32_t)(j * 256);
                 B32_STAMP(P_MTOP);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -565,14 +568,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                     f32x4 bb[2];
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh)
-                        bb[hh] = __builtin_bit_cast(f32x4, lds_read_b128_asm(b1_base + (uint32_t)((j * 64 + (2 * s + hh) * 4) * 4)));
+                        bb[hh] = __builtin_bit_cast(f32x4, lds_read_b128_asm_off(b1j, (2 * s + hh) * 16));
                     // fragments three K-steps ahead: a step is only 4 MFMAs (64 cycles) and an LDS read under load takes
                     // 150-250 (stamps: FC1 ran at 3x its MFMA time with two steps of lookahead)
                     bf16x8 wf[4][2];
                     auto ld1 = [&](int step, int slot) {
-                        const uint32_t a = wb1 + ((w_off ^ ((uint32_t)(step & 1) << 6)) + (uint32_t)((step >> 1) * (64 * 128) + 2 * s * 2048));
-                        wf[slot][0] = lds_read_b128_asm(a);
-                        wf[slot][1] = lds_read_b128_asm(a + 2048);
+                        const int off = (step >> 1) * (64 * 128) + 2 * s * 2048;
+                        wf[slot][0] = (step & 1) ? lds_read_b128_asm_off(w1a1, off) : lds_read_b128_asm_off(w1a0, off);
+                        wf[slot][1] = (step & 1) ? lds_read_b128_asm_off(w1a1, off + 2048) : lds_read_b128_asm_off(w1a0, off + 2048);
                     };
                     __builtin_amdgcn_sched_barrier(0);
                     ld1(0, 0);
@@ -602,10 +605,12 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                     }
                     B32_STAMP(P_W2BAR);
                     bf16x8 w2f[8];
-                    const uint32_t w2a = sbase + (s ? w2_off1 : w2_off0);
-                    auto w2addr = [&](int n) { return w2a + (uint32_t)((n >> 2) * (64 * 128) + (n & 3) * 2048); };
+                    auto w2rd = [&](int n) {
+                        const int off = (n >> 2) * (64 * 128) + (n & 3) * 2048;
+                        return s ? lds_read_b128_asm_off(w2a1, off) : lds_read_b128_asm_off(w2a0, off);
+                    };
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) w2f[n] = lds_read_b128_asm(w2addr(n));
+                    for (int n = 0; n < 8; ++n) w2f[n] = w2rd(n);
                     __builtin_amdgcn_sched_barrier(0);
                     bf16x8 hfr[2];
 #pragma unroll
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                         for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32(w2f[n], hfr[tg], acc2[tg][n]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) w2f[n] = lds_read_b128_asm(w2addr(8 + n));
+                    for (int n = 0; n < 4; ++n) w2f[n] = w2rd(8 + n);
                     lds_wait<4>();
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

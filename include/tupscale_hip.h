@@ -378,6 +378,12 @@ int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwi
  * (gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2); it is copied into the kernel arguments. */
 int tup_fused_blocks64_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
 
+/* Re-packing the weights after an optimizer step (training; replaces the torch index / permute / cat / cast calls of
+ * packing.py that follow reference train.py:139 `optimizer.step()`): dst[i] = map[i] < 0 ? 0 : concat(src[0..nparam-1])[map[i]].
+ * src: device array of nparam device pointers to the fp32 parameters; offs: device int [nparam + 1] prefix sum of their sizes;
+ * map: device int [n] (built once by pack_plan.py from packing.py itself); dst: bf16 (to_bf16 != 0, round to nearest even) or fp32 [n]. */
+int tup_pack_gather(const void* src, const int* offs, int nparam, const int* map, void* dst, long long n, int to_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

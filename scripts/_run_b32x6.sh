@@ -1,4 +1,4 @@
-timeout -k 10 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "kernels or hip_model or parity or hip_rt or window" > gpurun_out/r2_t3.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu -q -x -p no:cacheprovider -k "train or window or rt or dp" > gpurun_out/r2_t3.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/r2_t3.log
 grep -E "passed|failed|rc=|^E " gpurun_out/r2_t3.log | head -30
-grep -q "rc=0" gpurun_out/r2_t3.log && timeout -k 10 200 python bench.py --steps 30 --warmup 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['ms_per_launch'], d['roofline']['frac'])"
+grep -q "rc=0" gpurun_out/r2_t3.log && timeout -k 10 300 python bench.py --mode train --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-300 && TUP_NO_PACK_PLAN=1 timeout -k 10 300 python bench.py --mode train --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-200 && timeout -k 10 300 python bench.py --mode rt 2>/dev/null | tail -1 | cut -c1-200 && TUP_NO_PACK_PLAN=1 timeout -k 10 300 python bench.py --mode rt 2>/dev/null | tail -1 | cut -c1-200

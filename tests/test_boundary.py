@@ -215,3 +215,23 @@ def test_stride2_dgrad_packing_matches_autograd():
     assert (got - x.grad).abs().max() <= 1e-4 * max(1.0, x.grad.abs().max().item())
     dwp = torch.zeros(4, 64, 9, 64)
     assert torch.equal(packing.unpack_conv_c64_stride2_wgrad(dwp), torch.zeros(64, 64, 3, 3))
+
+
+def test_pack_plan_maps_on_cpu(det_sd):
+    """The bit-plane trace of pack_plan.PackPlan (no GPU needed to BUILD a plan): applying its maps with torch indexing
+    reproduces packing.pack_state_dict(backward=True) bit for bit -- i.e. every training-time packed tensor is a pure
+    gather of the parameters and the traced maps are the right ones."""
+    import importlib
+    from transformerupscaler_amd import packing
+    from transformerupscaler_amd.pack_plan import PackPlan
+    m = importlib.import_module("models.FastTransformer.model").TransformerModel()
+    m.load_state_dict(det_sd, strict=False)
+    params = list(m.named_parameters())
+    plan = PackPlan(params, lambda d: packing.pack_state_dict(d, 2, backward=True))
+    flat = torch.cat([p.detach().reshape(-1) for _, p in params])
+    ref = packing.pack_state_dict(dict(params), 2, backward=True)
+    assert set(ref) == set(plan.views)
+    for k, (dt, off, shape) in plan.views.items():
+        mp = (plan.map_bf16 if dt == torch.bfloat16 else plan.map_f32)[off:off + ref[k].numel()].long()
+        got = torch.where(mp >= 0, flat[mp.clamp(min=0)], torch.zeros(())).to(dt).view(shape)
+        assert ref[k].dtype == dt and torch.equal(got, ref[k]), k

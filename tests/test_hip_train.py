@@ -180,3 +180,31 @@ def test_l1_loss_kernels_match_torch(shape):
     assert torch.equal(a.grad, a2.grad)
     with pytest.raises(ValueError):
         l1_loss(a, b.reshape(1, -1))
+
+
+@pytest.mark.parametrize("scale", [2, 3, 4, 6])
+def test_pack_plan_equals_torch_pack(det_sd, scale):
+    """pack_plan.PackPlan (two tup_pack_gather launches, maps traced from packing.py) == packing.pack_state_dict(backward=True),
+    bit for bit, on the loaded weights and again after an in-place update of every parameter (what Adam does, train.py:139);
+    and the module's training path uses it."""
+    from transformerupscaler_amd import packing
+    from transformerupscaler_amd.pack_plan import PackPlan
+    model = make_model(det_sd)
+    params = list(model.named_parameters())
+    plan = PackPlan(params, lambda d: packing.pack_state_dict(d, scale, backward=True))
+    g = torch.Generator(device="cuda").manual_seed(scale)
+    for rnd in range(2):
+        ref = packing.pack_state_dict(dict(params), scale, backward=True)
+        got = plan.run(params)
+        assert set(ref) == set(got)
+        for k in ref:
+            assert ref[k].dtype == got[k].dtype and ref[k].shape == got[k].shape, k
+            assert torch.equal(ref[k], got[k]), k
+            assert got[k].data_ptr() % 16 == 0, k                  # the kernels read them with 16-byte loads
+        with torch.no_grad():
+            for _, p in params:
+                p.add_(torch.randn(p.shape, device="cuda", generator=g) * 0.01)
+    pk, _, _ = model.packed(scale, backward=True)
+    assert isinstance(model._pack_plans[scale], PackPlan)
+    ref = packing.pack_state_dict(dict(params), scale, backward=True)
+    assert all(torch.equal(pk[k], ref[k]) for k in ref)

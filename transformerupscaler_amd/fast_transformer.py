@@ -21,6 +21,7 @@ from .weights import VALID_SCALES, upsampler_layout
 
 # training: run the last x2 Upsampler stage + up1_conv (and their backward) through the exact composition; False = explicit kernels
 compose_branch_a_in_training = not os.environ.get("TUP_NO_COMPOSED_TRAIN")
+use_pack_plan = not os.environ.get("TUP_NO_PACK_PLAN")          # training re-pack as two gather launches (pack_plan.py)
 
 
 class _ConvParams(nn.Module):
@@ -160,6 +161,13 @@ class TransformerModel(nn.Module):
         ``.to()`` are detected automatically."""
         self._pack_cache = {}
 
+    def _pack_with_plan(self, sd, scale: int):
+        """Training re-pack (once per optimizer step) through pack_plan.PackPlan: two gather launches instead of packing.py's
+        ~75 torch launches.  The plan is traced from packing.pack_state_dict itself and verified bit for bit against it on the
+        current weights before its first use; None (torch path) if it cannot be built."""
+        from .pack_plan import packed_with_plan
+        return packed_with_plan(self, scale, sd, lambda d: packing.pack_state_dict(d, scale, backward=True))
+
     def packed(self, scale: int, backward: bool = False):
         """Packed weights (+ dense relative-position biases) for `scale`; re-packed when any parameter
         was updated in place (optimizer step) or moved."""
@@ -168,7 +176,9 @@ class TransformerModel(nn.Module):
         hit = self._pack_cache.get(key)
         if hit is None or hit[0] != ver:
             sd = {k: v for k, v in self.named_parameters()}
-            pk = packing.pack_state_dict(sd, scale, backward=backward)
+            pk = self._pack_with_plan(sd, scale) if backward and use_pack_plan else None
+            if pk is None:
+                pk = packing.pack_state_dict(sd, scale, backward=backward)
             nb = len(self.window_blocks)
             frags_t = [ops.relpos_bias_expand(pk[f"b{i}.table"]) for i in range(nb)]
             frags_n = [ops.relpos_bias_expand_n(pk[f"b{i}.table"]) for i in range(nb)] if backward else None

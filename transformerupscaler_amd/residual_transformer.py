@@ -10,6 +10,7 @@ attention probabilities and the MLP output, reference model.py:30,37).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -79,7 +80,11 @@ class TransformerModel(nn.Module):
         ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
         hit = self._pack_cache.get(bool(backward))
         if hit is None or hit[0] != ver:
-            hit = (ver, packing.pack_rt_state_dict(dict(self.named_parameters()), backward=backward))
+            sd, pk = dict(self.named_parameters()), None
+            if backward and not os.environ.get("TUP_NO_PACK_PLAN"):       # training: re-pack = two gather launches (pack_plan.py)
+                from .pack_plan import packed_with_plan
+                pk = packed_with_plan(self, "rt", sd, lambda d: packing.pack_rt_state_dict(d, backward=True))
+            hit = (ver, pk if pk is not None else packing.pack_rt_state_dict(sd, backward=backward))
             self._pack_cache[bool(backward)] = hit
         return hit[1]
 

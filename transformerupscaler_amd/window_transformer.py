@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -58,7 +60,12 @@ class TransformerModel(nn.Module):
         ver = tuple((p.data_ptr(), p._version) for p in self.parameters())
         hit = self._pack_cache.get(bool(backward))
         if hit is None or hit[0] != ver:
-            pk = packing.pack_wt_state_dict(dict(self.named_parameters()), backward=backward)
+            sd, pk = dict(self.named_parameters()), None
+            if backward and not os.environ.get("TUP_NO_PACK_PLAN"):       # training: re-pack = two gather launches (pack_plan.py)
+                from .pack_plan import packed_with_plan
+                pk = packed_with_plan(self, "wt", sd, lambda d: packing.pack_wt_state_dict(d, backward=True))
+            if pk is None:
+                pk = packing.pack_wt_state_dict(sd, backward=backward)
             frags = [ops.relpos_bias_expand_h(pk[f"b{i}.table"], self.num_heads) for i in range(pk["nblocks"])]
             entry = (ver, pk, frags)
             if backward:

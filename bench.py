@@ -385,7 +385,8 @@ def main():
                   "achieved": attn_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / MFMA_BF16_PEAK_TFLOPS,
                   "traffic": blk_traffic, "traffic_source": blk_src,
                   "algorithmic_flop_per_launch": ATTN_SET_FLOP_PER_IMAGE * args.batch / n_block_launch,
-                  "algorithmic_bytes": nwin * 64 * 192 * 4 * 2,       # per launch: the fp32 residual stream read once + written once
+                  # SURVEY 8(d)'s per-block figure (the fp32 residual stream read once + written once) x the blocks one launch runs
+                  "algorithmic_bytes": nwin * 64 * 192 * 4 * 2 * (6 // n_block_launch),
                   "ms_per_launch": blk_ms, "total_ms_per_forward": blocks_ms, "launches_timed": len(block_events) * n_block_launch,
                   "note": "algorithmic FLOPs = SURVEY 8(d)'s window-attention GEMM set (qkv, QK^T, PV, proj, fc1, fc2 = 86.1 GF per image); "
                           "LayerNorm / softmax / GELU run inside the same launches and are not counted; north_star target frac >= 0.40"}

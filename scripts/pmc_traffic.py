@@ -11,7 +11,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {  # bench.py key -> (substring of the kernel name, source file, algorithmic bytes per launch at B = 8 or None)
-    "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 1920 * 64 * 192 * 4 * 2),
+    "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 1920 * 64 * 192 * 4 * 2),   # six blocks per launch
     "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 8 * 720 * 1280 * 64 * 2),
     "tail": ("tail_fused_kernel", "tail_fused.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
     "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", None),

@@ -33,9 +33,11 @@ class PackPlan:
         if total + 1 >= 2 ** 31:
             raise ValueError("parameter count exceeds the int32 maps")
         self.total = total
-        # ---- trace: one pack per bit of (flat index + 1) ----
+        # ---- trace: one pack per bit of (flat index + 1), on the host (packing.py is device-agnostic; this keeps a few thousand
+        #      tiny launches off the GPU -- the plan is built inside the first training step) ----
         nbits = int(total + 1).bit_length()
-        ids = torch.arange(1, total + 1, device=dev, dtype=torch.int64)
+        cpu = torch.device("cpu")
+        ids = torch.arange(1, total + 1, dtype=torch.int64)
         acc: Dict[str, torch.Tensor] = {}
         self.consts: Dict[str, object] = {}
         meta: Dict[str, Tuple[torch.dtype, Tuple[int, ...]]] = {}
@@ -51,8 +53,8 @@ class PackPlan:
                     if t.dtype not in (torch.bfloat16, torch.float32):
                         raise TypeError(f"packed tensor {k}: unexpected dtype {t.dtype}")
                     meta[k] = (t.dtype, tuple(t.shape))
-                    acc[k] = torch.zeros(t.numel(), device=dev, dtype=torch.int64)
-                v = t.reshape(-1).to(torch.float32)
+                    acc[k] = torch.zeros(t.numel(), dtype=torch.int64)
+                v = t.reshape(-1).to(device=cpu, dtype=torch.float32)
                 if not bool(((v == 0) | (v == 1)).all()):
                     raise ValueError(f"packed tensor {k} is not a pure gather of the parameters")
                 acc[k] |= v.to(torch.int64) << b
@@ -64,13 +66,13 @@ class PackPlan:
             align = 128 if dt == torch.bfloat16 else 64
             pad = (-fill[dt]) % align
             if pad:
-                maps[dt].append(torch.full((pad,), -1, device=dev, dtype=torch.int32))
+                maps[dt].append(torch.full((pad,), -1, dtype=torch.int32))
                 fill[dt] += pad
             self.views[k] = (dt, fill[dt], shape)
             maps[dt].append((acc[k] - 1).to(torch.int32))
             fill[dt] += acc[k].numel()
-        self.map_bf16 = torch.cat(maps[torch.bfloat16]) if maps[torch.bfloat16] else torch.empty(0, device=dev, dtype=torch.int32)
-        self.map_f32 = torch.cat(maps[torch.float32]) if maps[torch.float32] else torch.empty(0, device=dev, dtype=torch.int32)
+        self.map_bf16 = (torch.cat(maps[torch.bfloat16]) if maps[torch.bfloat16] else torch.empty(0, dtype=torch.int32)).to(dev)
+        self.map_f32 = (torch.cat(maps[torch.float32]) if maps[torch.float32] else torch.empty(0, dtype=torch.int32)).to(dev)
         self.offs = torch.tensor(offs, device=dev, dtype=torch.int32)
         self._ptrs_host: List[int] = []
         self._ptrs = torch.zeros(len(params), device=dev, dtype=torch.int64)

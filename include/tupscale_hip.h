@@ -198,9 +198,12 @@ int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const f
 /* Dense relative-position bias in the second (query-row) fragment order used by the backward. */
 int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream);
 
-/* Attention-core backward (recomputes P): gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] +=. */
+/* Attention-core backward (recomputes P): gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] overwritten (the dense
+ * gradient of the relative-position bias).  scratch: fp32 [tup_window_attn_bwd_scratch(nwin, heads)], uninitialised -- each
+ * persistent wave writes its own partial sum there and a second kernel adds the slots up (no float atomics). */
 int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                        void* gqkv, float* dbias_t, int nwin, float drop_p, unsigned int drop_seed, void* stream);
+                        void* gqkv, float* dbias_t, float* scratch, int nwin, float drop_p, unsigned int drop_seed, void* stream);
+long long tup_window_attn_bwd_scratch(int nwin, int heads);
 
 /* Backward of nn.Dropout after proj / mlp.2: gout bf16 = gin fp32 * mask / (1 - p), element index m*192+n. */
 int tup_dropout_bwd(const float* gin, void* gout, long long n, float drop_p, unsigned int drop_seed, void* stream);
@@ -306,7 +309,7 @@ int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga
  * gradient on the floor(H/8) x floor(W/8) token grid (out fp32 [NI][4096] += P^T patches(map), no reflect padding). */
 int tup_relpos_bias_expand_n_h(const float* table, float* frag, int heads, void* stream);
 int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t, const float* bias_n, void* gqkv,
-                          float* dbias_t, int nwin, int heads, float drop_p, unsigned int drop_seed, void* stream);
+                          float* dbias_t, float* scratch, int nwin, int heads, float drop_p, unsigned int drop_seed, void* stream);
 int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int heads, void* stream);
 int tup_wt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int NI, void* stream);
 

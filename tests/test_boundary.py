@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from transformerupscaler_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "tupscale_hip.h")).read()
-    declared = set(re.findall(r"\b(?:int)\s+(tup_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(?:int|long long)\s+(tup_\w+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()                      # raises if the .so or any symbol is missing

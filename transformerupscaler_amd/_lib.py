@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 P = c_void_p
 I = c_int
@@ -48,7 +48,7 @@ SIGNATURES = {
     "tup_rt_bicubic_bwd": [P] * 10 + [I, I, I, I, I, P],
     "tup_relpos_bias_expand_h": [P, P, I, P],
     "tup_relpos_bias_expand_n_h": [P, P, I, P],
-    "tup_window_attn_bwd_h": [P, P, P, P, P, P, I, I, F, U, P],
+    "tup_window_attn_bwd_h": [P, P, P, P, P, P, P, I, I, F, U, P],
     "tup_relpos_bias_reduce_h": [P, P, I, P],
     "tup_wt_patch_wgrad": [P, P, P, I, I, I, I, P],
     "tup_window_attn_fwd_h": [P, P, P, I, I, F, U, P],
@@ -77,7 +77,8 @@ SIGNATURES = {
     "tup_colsum": [P, I, I, P, I, I, P, P],
     "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand_n": [P, P, P],
-    "tup_window_attn_bwd": [P, P, P, P, P, P, I, F, U, P],
+    "tup_window_attn_bwd": [P, P, P, P, P, P, P, I, F, U, P],
+    "tup_window_attn_bwd_scratch": [I, I],
     "tup_dropout_bwd": [P, P, c_longlong, F, U, P],
     "tup_relpos_bias_reduce": [P, P, P],
     "tup_patch_unembed_bwd": [P, P, P, I, I, I, P],
@@ -100,6 +101,9 @@ class TupscaleLibraryError(RuntimeError):
 _lib = None
 
 
+COUNT_RETURNING = {"tup_window_attn_bwd_scratch"}      # return an element count, not a hipError_t
+
+
 def load():
     """Load the HIP library once; raise TupscaleLibraryError (never fall back) if unusable."""
     global _lib
@@ -120,7 +124,7 @@ def load():
         except AttributeError as e:
             raise TupscaleLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name in COUNT_RETURNING else c_int
     if lib.tup_abi_version() != ABI_VERSION:
         raise TupscaleLibraryError(f"ABI mismatch: library {lib.tup_abi_version()} != binding {ABI_VERSION}; rebuild")
     _lib = lib

@@ -151,7 +151,7 @@ TUP_DEVICE s16x4 to_bf16x4(const f32x4 v) {
 template <int HEADS>
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ gout, const float* __restrict__ bias_t,
-    const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_t, int nwin, int nslots,
+    const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_part, int nwin, int nslots,
     uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
     constexpr int DIM = HEADS * HD;
@@ -320,13 +320,15 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
         wave_lds_sync();      // LDS tiles are overwritten by the next window
     }
 
+    // this wave's dS sum goes to ITS OWN slice of the scratch buffer with plain stores ([slot][h][kt][qt][lane][4]); the slots are
+    // summed by dbias_sum_kernel.  (Float atomics straight into dbias_t -- every wave of a head adding to the same 4,096
+    // addresses, 128-way -- were 49 of the kernel's 245 us.)
+    float* part = dbias_part + ((size_t)slot * HEADS + h) * 4096;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                atomicAdd(dbias_t + ((((size_t)h * 4 + kt) * 4 + qt) * 64 + lane) * 4 + e, dbacc[kt][qt][e]);
+            *reinterpret_cast<f32x4*>(part + (((size_t)kt * 4 + qt) * 64 + lane) * 4) = dbacc[kt][qt];
 }
 
 // gd = g * mask/keep (element index m*192 + n): gradient through proj_drop / the MLP's Dropout
@@ -395,16 +397,37 @@ extern "C" int tup_relpos_bias_expand_n(const float* table, float* frag, void* s
 }
 
 namespace {
+// dbias_t[i] = sum over slots of part[slot][i], i < n4 float4s: 64 float4 columns x 4 slot groups per workgroup, LDS-combined
+__global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict__ part, float* __restrict__ dbias_t, int n4, int nslots)
+{
+    __shared__ f32x4 red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < n4)
+        for (int s = grp; s < nslots; s += 4) acc += reinterpret_cast<const f32x4*>(part)[(size_t)s * n4 + col];
+    red[grp][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (grp == 0 && col < n4)
+        reinterpret_cast<f32x4*>(dbias_t)[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+constexpr int ATTN_BWD_MAX_SLOTS = 128;
+inline int attn_bwd_slots(int nwin) { return nwin < ATTN_BWD_MAX_SLOTS ? nwin : ATTN_BWD_MAX_SLOTS; }
+
 template <int HEADS>
 int launch_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n, void* gqkv, float* dbias_t,
-                    int nwin, float drop_p, unsigned int drop_seed, hipStream_t s)
+                    float* scratch, int nwin, float drop_p, unsigned int drop_seed, hipStream_t s)
 {
+    if (scratch == nullptr) return (int)hipErrorInvalidValue;
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    int nslots = nwin < 128 ? nwin : 128;
+    const int nslots = attn_bwd_slots(nwin);
     const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
     window_attn_bwd_kernel<HEADS><<<dim3(nwaves / 4), dim3(256), 0, s>>>(
-        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, dbias_t, nwin, nslots,
+        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, scratch, nwin, nslots,
         thresh, 1.0f / (1.0f - drop_p), drop_seed);
+    TUP_CHECK_LAUNCH();
+    const int n4 = HEADS * 1024;
+    dbias_sum_kernel<<<dim3(n4 / 64), dim3(256), 0, s>>>(scratch, dbias_t, n4, nslots);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -423,14 +446,14 @@ extern "C" int tup_relpos_bias_expand_n_h(const float* table, float* frag, int h
 }
 
 extern "C" int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                                     void* gqkv, float* dbias_t, int nwin, int heads, float drop_p, unsigned int drop_seed,
-                                     void* stream)
+                                     void* gqkv, float* dbias_t, float* scratch, int nwin, int heads, float drop_p,
+                                     unsigned int drop_seed, void* stream)
 {
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (heads == 12) return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, nwin, drop_p, drop_seed, s);
-    if (heads == 8) return launch_attn_bwd<8>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, nwin, drop_p, drop_seed, s);
+    if (heads == 12) return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, scratch, nwin, drop_p, drop_seed, s);
+    if (heads == 8) return launch_attn_bwd<8>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, scratch, nwin, drop_p, drop_seed, s);
     return (int)hipErrorInvalidValue;
 }
 
@@ -445,14 +468,21 @@ extern "C" int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int
 }
 
 // qkv bf16 [nwin][64][576], gout bf16 [nwin][64][192] (grad of the attention output before proj) ->
-// gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] accumulated (caller zeroes).
+// gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] overwritten; scratch fp32 [tup_window_attn_bwd_scratch(nwin, 12)]
+// (per-wave partial sums of the bias gradient, no initialisation needed).
 extern "C" int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                                   void* gqkv, float* dbias_t, int nwin, float drop_p, unsigned int drop_seed,
+                                   void* gqkv, float* dbias_t, float* scratch, int nwin, float drop_p, unsigned int drop_seed,
                                    void* stream)
 {
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
-    return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, nwin, drop_p, drop_seed, reinterpret_cast<hipStream_t>(stream));
+    return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, scratch, nwin, drop_p, drop_seed, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Floats of scratch tup_window_attn_bwd(_h) needs for nwin windows and `heads` heads.
+extern "C" long long tup_window_attn_bwd_scratch(int nwin, int heads)
+{
+    return nwin <= 0 ? 0 : (long long)attn_bwd_slots(nwin) * heads * 4096;
 }
 
 // dense T-layout bias gradient -> relative_position_bias_table gradient fp32 [225][12] (overwritten).

@@ -432,15 +432,22 @@ def dropout_bwd(g, drop_p, drop_seed):
     return out
 
 
+def _attn_bwd_scratch(nwin, heads):
+    """Floats of scratch the attention backward needs (tup_window_attn_bwd_scratch returns the count, not an error code)."""
+    fn = _lib.load().tup_window_attn_bwd_scratch
+    return int(fn(int(nwin), int(heads)))
+
+
 def window_attn_bwd(qkv, gout, bias_t, bias_n, drop_p=0.0, drop_seed=0):
     """returns (gqkv bf16 [M][576], dtable fp32 [225][12])."""
     M = qkv.shape[0]
     assert M % 64 == 0
     gqkv = torch.empty((M, 576), dtype=BF16, device=qkv.device)
-    dbias = _zeros((12, 4, 4, 64, 4), qkv.device)
+    dbias = torch.empty((12, 4, 4, 64, 4), dtype=F32, device=qkv.device)
+    scratch = torch.empty(_attn_bwd_scratch(M // 64, 12), dtype=F32, device=qkv.device)
     _lib.call("tup_window_attn_bwd", _chk(qkv, BF16, (M, 576), "qkv"), _chk(gout, BF16, (M, 192), "gout"),
               _chk(bias_t, F32, (12, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (12, 4, 4, 64, 4), "bias_n"),
-              gqkv.data_ptr(), dbias.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+              gqkv.data_ptr(), dbias.data_ptr(), scratch.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     dtable = torch.empty((225, 12), dtype=F32, device=qkv.device)
     _lib.call("tup_relpos_bias_reduce", dbias.data_ptr(), dtable.data_ptr(), _stream())
     return gqkv, dtable
@@ -882,10 +889,11 @@ def window_attn_bwd_h(qkv, gout, bias_t, bias_n, heads, drop_p=0.0, drop_seed=0)
     M = qkv.shape[0]
     assert M % 64 == 0
     gqkv = torch.empty((M, 48 * heads), dtype=BF16, device=qkv.device)
-    dbias = _zeros((heads, 4, 4, 64, 4), qkv.device)
+    dbias = torch.empty((heads, 4, 4, 64, 4), dtype=F32, device=qkv.device)
+    scratch = torch.empty(_attn_bwd_scratch(M // 64, heads), dtype=F32, device=qkv.device)
     _lib.call("tup_window_attn_bwd_h", _chk(qkv, BF16, (M, 48 * heads), "qkv"), _chk(gout, BF16, (M, 16 * heads), "gout"),
               _chk(bias_t, F32, (heads, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (heads, 4, 4, 64, 4), "bias_n"),
-              gqkv.data_ptr(), dbias.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+              gqkv.data_ptr(), dbias.data_ptr(), scratch.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     dtable = torch.empty((225, heads), dtype=F32, device=qkv.device)
     _lib.call("tup_relpos_bias_reduce_h", dbias.data_ptr(), dtable.data_ptr(), heads, _stream())
     return gqkv, dtable

@@ -205,6 +205,7 @@ def test_pack_plan_equals_torch_pack(det_sd, scale):
             for _, p in params:
                 p.add_(torch.randn(p.shape, device="cuda", generator=g) * 0.01)
     pk, _, _ = model.packed(scale, backward=True)
-    assert isinstance(model._pack_plans[scale], PackPlan)
+    from transformerupscaler_amd import pack_plan
+    assert any(isinstance(v, PackPlan) and k[1] == scale for k, v in pack_plan._PLANS.items())      # the module's path uses a plan
     ref = packing.pack_state_dict(dict(params), scale, backward=True)
     assert all(torch.equal(pk[k], ref[k]) for k in ref)

@@ -3,9 +3,9 @@
 `packing.pack_state_dict(..., backward=True)` turns the module's parameters into the layouts the kernels read.  Every one of
 its outputs is a pure gather of parameter elements (permute / index_select / flip / cat / zero padding / dtype cast) -- no
 arithmetic -- so there is one integer map per output: element i <- parameter element map[i] (or zero).  The map is not
-written by hand a second time: it is DERIVED from packing.py by tracing.  The pack is run once per bit of the (1-based) flat
-parameter index with every parameter holding that bit of its own index (0.0 / 1.0, exact in bf16); the packed outputs then
-hold the bits of their source indices.  The plan is checked against a real pack of the real weights (bit-equal) before its
+written by hand a second time: it is DERIVED from packing.py by tracing.  The pack is run once per base-256 digit of the
+(1-based) flat parameter index with every parameter holding that digit of its own indices (0..255 are exact in bf16, so the
+digits survive the casts); the packed outputs then hold the digits of their source indices -- three packs, on the host.  The plan is checked against a real pack of the real weights (bit-equal) before its
 first use, so a packing function that stops being a pure gather is caught (the module then keeps the torch path).
 
 Per step this replaces ~75 aten launches (reference train.py:139 moves every weight, so the pack runs once per step) by
@@ -33,31 +33,32 @@ class PackPlan:
         if total + 1 >= 2 ** 31:
             raise ValueError("parameter count exceeds the int32 maps")
         self.total = total
-        # ---- trace: one pack per bit of (flat index + 1), on the host (packing.py is device-agnostic; this keeps a few thousand
-        #      tiny launches off the GPU -- the plan is built inside the first training step) ----
-        nbits = int(total + 1).bit_length()
+        # ---- trace: one pack per base-256 digit of (flat index + 1), on the host (packing.py is device-agnostic; this keeps the
+        #      tracing launches off the GPU -- the plan is built inside the first training step) ----
+        ndig = (int(total + 1).bit_length() + 7) // 8         # base-256 digits: 0..255 are exact in bf16 (8-bit significand)
         cpu = torch.device("cpu")
         ids = torch.arange(1, total + 1, dtype=torch.int64)
         acc: Dict[str, torch.Tensor] = {}
         self.consts: Dict[str, object] = {}
         meta: Dict[str, Tuple[torch.dtype, Tuple[int, ...]]] = {}
-        for b in range(nbits):
-            plane = ((ids >> b) & 1).to(torch.float32)
+        for d in range(ndig):
+            plane = ((ids >> (8 * d)) & 255).to(torch.float32)
             sd = {n: plane[offs[i]:offs[i + 1]].view(self.shapes[i]) for i, n in enumerate(self.names)}
             out = pack_fn(sd)
             for k, t in out.items():
                 if not torch.is_tensor(t):                # constants of the layout (e.g. a block count) pass through
                     self.consts[k] = t
                     continue
-                if b == 0:
+                if d == 0:
                     if t.dtype not in (torch.bfloat16, torch.float32):
                         raise TypeError(f"packed tensor {k}: unexpected dtype {t.dtype}")
                     meta[k] = (t.dtype, tuple(t.shape))
                     acc[k] = torch.zeros(t.numel(), dtype=torch.int64)
                 v = t.reshape(-1).to(device=cpu, dtype=torch.float32)
-                if not bool(((v == 0) | (v == 1)).all()):
+                vi = v.to(torch.int64)
+                if not bool(((vi.to(torch.float32) == v) & (vi >= 0) & (vi <= 255)).all()):
                     raise ValueError(f"packed tensor {k} is not a pure gather of the parameters")
-                acc[k] |= v.to(torch.int64) << b
+                acc[k] |= vi << (8 * d)
         # ---- layout: all bf16 outputs in one buffer, all fp32 outputs in another (each tensor 256-byte aligned) ----
         self.views: Dict[str, Tuple[torch.dtype, int, Tuple[int, ...]]] = {}
         maps = {torch.bfloat16: [], torch.float32: []}
@@ -110,18 +111,21 @@ class PackPlan:
         return pk
 
 
+_PLANS: Dict[tuple, object] = {}          # process-wide: a plan depends on the layout (names, shapes, pack function), not on the values
+
+
 def packed_with_plan(module, key, sd: Dict[str, torch.Tensor], pack_fn):
-    """pack_fn(sd) through a PackPlan cached on `module` under `key`: built on first use, verified bit for bit against pack_fn on
-    the current weights, rebuilt when the parameters move (.to()); None when no plan applies (CPU tensors, a non-gather pack) --
-    the caller then runs pack_fn itself."""
+    """pack_fn(sd) through a PackPlan: built once per process and layout (`key` names the pack function, e.g. ("ft", scale)),
+    verified bit for bit against pack_fn on the weights it is first used with; None when no plan applies (CPU tensors, a
+    non-gather pack) -- the caller then runs pack_fn itself.  `module` only scopes the key (its class name is part of it)."""
     params = list(sd.items())
     if not params or not params[0][1].is_cuda or any(p.dtype != torch.float32 or not p.is_contiguous() for _, p in params):
         return None
-    plans = module.__dict__.setdefault("_pack_plans", {})
-    plan = plans.get(key)
+    ck = (type(module).__name__, key, params[0][1].device, tuple(n for n, _ in params), tuple(tuple(p.shape) for _, p in params))
+    plan = _PLANS.get(ck)
     if plan is False:
         return None
-    if plan is not None and plan.matches(params):
+    if plan is not None:
         return plan.run(params)
     try:
         plan = PackPlan(params, pack_fn)
@@ -130,5 +134,5 @@ def packed_with_plan(module, key, sd: Dict[str, torch.Tensor], pack_fn):
             (ref[k].dtype == got[k].dtype and torch.equal(ref[k], got[k])) if torch.is_tensor(ref[k]) else ref[k] == got[k] for k in ref)
     except (ValueError, TypeError):
         ok = False
-    plans[key] = plan if ok else False
+    _PLANS[ck] = plan if ok else False
     return got if ok else None

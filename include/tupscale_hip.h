@@ -387,6 +387,12 @@ int tup_fused_blocks64_fwd(float* x, const void* const* table, int nblk, int nwi
  * map: device int [n] (built once by pack_plan.py from packing.py itself); dst: bf16 (to_bf16 != 0, round to nearest even) or fp32 [n]. */
 int tup_pack_gather(const void* src, const int* offs, int nparam, const int* map, void* dst, long long n, int to_bf16, void* stream);
 
+/* torch.optim.Adam's step (reference train.py:104,139; default betas / eps, no weight decay, no amsgrad) for all parameters in one
+ * launch.  segs: device array [nseg] of 64-byte records {float* p; const float* g; float* m; float* v; long long n; float step_size
+ * (= lr / bias_correction1), inv_sqrt_bc2 (= 1 / sqrt(bias_correction2)), beta2, 1 - beta1, 1 - beta2, eps}; chunks: device int [nchunks][2] =
+ * (segment index, first element), one workgroup per 4096 elements.  p, m, v are updated in place. */
+int tup_adam_step(const void* segs, const int* chunks, int nchunks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

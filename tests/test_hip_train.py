@@ -209,3 +209,53 @@ def test_pack_plan_equals_torch_pack(det_sd, scale):
     assert any(isinstance(v, PackPlan) and k[1] == scale for k, v in pack_plan._PLANS.items())      # the module's path uses a plan
     ref = packing.pack_state_dict(dict(params), scale, backward=True)
     assert all(torch.equal(pk[k], ref[k]) for k in ref)
+
+
+def test_fused_adam_equals_torch_adam():
+    """optim.Adam (one tup_adam_step launch) against torch.optim.Adam on the same parameters and gradients: three steps with a
+    parameter that has no gradient in step 2 (skipped: its step count and moments must not move), two parameter groups
+    with different learning rates, and the state_dict of one loading into the other."""
+    from transformerupscaler_amd.optim import Adam
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = [(64, 3, 3, 3), (192,), (5000,), (768, 192), (1,)]
+    base = [torch.randn(s, device="cuda", generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(b.clone()) for b in base]
+    pb = [torch.nn.Parameter(b.clone()) for b in base]
+    oa = Adam([{"params": pa[:3], "lr": 1e-3}, {"params": pa[3:], "lr": 3e-4}])
+    ob = torch.optim.Adam([{"params": pb[:3], "lr": 1e-3}, {"params": pb[3:], "lr": 3e-4}])
+    for step in range(3):
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            if step == 1 and i == 2:
+                x.grad = y.grad = None
+                continue
+            gr = torch.randn(x.shape, device="cuda", generator=g)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert torch.allclose(x, y, rtol=2e-6, atol=1e-7), (step, i, (x - y).abs().max().item())
+            sa, sb = oa.state[x], ob.state[y]
+            assert float(sa["step"]) == float(sb["step"])
+            assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=2e-6, atol=1e-8)
+            assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=2e-6, atol=1e-10)
+    assert float(oa.state[pa[2]]["step"]) == 2.0
+    # interchange: torch's state into the fused optimizer and back
+    oa2 = Adam([{"params": pa[:3], "lr": 1e-3}, {"params": pa[3:], "lr": 3e-4}])
+    oa2.load_state_dict(ob.state_dict())
+    ob2 = torch.optim.Adam([{"params": pb[:3], "lr": 1e-3}, {"params": pb[3:], "lr": 3e-4}])
+    ob2.load_state_dict(oa.state_dict())
+    for x, y in zip(pa, pb):
+        gr = torch.randn(x.shape, device="cuda", generator=g)
+        x.grad, y.grad = gr.clone(), gr.clone()
+    oa2.step(); ob2.step()
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=4e-6, atol=2e-7)
+    # options the kernel does not implement run torch's own step
+    pc = [torch.nn.Parameter(base[0].clone())]
+    oc = Adam(pc, lr=1e-3, weight_decay=0.1)
+    pc[0].grad = torch.ones_like(pc[0])
+    oc.step()
+    pd = [torch.nn.Parameter(base[0].clone())]
+    od = torch.optim.Adam(pd, lr=1e-3, weight_decay=0.1)
+    pd[0].grad = torch.ones_like(pd[0])
+    od.step()
+    assert torch.equal(pc[0], pd[0])

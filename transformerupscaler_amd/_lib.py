@@ -60,6 +60,7 @@ SIGNATURES = {
     "tup_fused_blocks64_fwd": [P, P, I, I, P],
     "tup_fused_blocks32_fwd": [P, P, I, I, P],
     "tup_pack_gather": [P, P, I, P, P, c_longlong, I, P],
+    "tup_adam_step": [P, P, I, P],
     "tup_l1_loss_partial": [P, P, P, c_longlong, I, P],
     "tup_l1_loss_bwd": [P, P, P, P, c_longlong, P],
     "tup_u8hwc_to_f32chw": [P, P, I, I, I, I, P],

@@ -50,3 +50,49 @@ extern "C" int tup_pack_gather(const void* src, const int* offs, int nparam, con
     TUP_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam's update (reference train.py:104,139: Adam, default betas / eps, no weight decay, no amsgrad) for ALL
+// parameters in one launch.  The parameters, their gradients and the two moment buffers stay separate tensors: a segment table
+// carries their base pointers and the step-dependent scalars, a chunk table maps workgroups to (segment, first element).
+//   m = m + (g - m) * (1 - beta1)                 (exp_avg.lerp_(grad, 1 - beta1))
+//   v = v * beta2 + g * g * (1 - beta2)           (exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2))
+//   p = p - step_size * m / (sqrt(v) / sqrt(bias_correction2) + eps),   step_size = lr / bias_correction1
+// Bound: HBM (4 reads + 3 writes of 4 B per element).
+// ------------------------------------------------------------------------------------------------
+struct AdamSeg {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    float step_size, inv_sqrt_bc2, beta2, omb1, omb2, eps;      // omb = 1 - beta, rounded from double on the host as torch does
+};
+static_assert(sizeof(AdamSeg) == 64, "segment record = 64 bytes (the host packs it as 8 int64 words)");
+
+namespace {
+constexpr int ADAM_CHUNK = 4096;
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamSeg* __restrict__ segs, const int* __restrict__ chunks)
+{
+    const int seg = chunks[2 * blockIdx.x], first = chunks[2 * blockIdx.x + 1];
+    const AdamSeg s = segs[seg];
+    const long long end = min((long long)first + ADAM_CHUNK, s.n);
+    const float omb1 = s.omb1, omb2 = s.omb2;
+    for (long long i = first + threadIdx.x; i < end; i += 256) {
+        const float g = s.g[i];
+        float m = s.m[i], v = s.v[i];
+        m = m + (g - m) * omb1;
+        v = v * s.beta2 + g * g * omb2;
+        const float denom = sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
+        s.m[i] = m; s.v[i] = v;
+        s.p[i] = s.p[i] - s.step_size * (m / denom);
+    }
+}
+}  // namespace
+
+// segs: device array [nseg] of 64-byte records {p, g, m, v (device pointers), n (int64), step_size, 1/sqrt(bias_correction2),
+// beta2, 1 - beta1, 1 - beta2, eps (fp32)}; chunks: device int [nchunks][2] = (segment, first element), 4096 elements per chunk.
+extern "C" int tup_adam_step(const void* segs, const int* chunks, int nchunks, void* stream)
+{
+    if (nchunks <= 0) return 0;
+    adam_step_kernel<<<dim3((unsigned)nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>((const AdamSeg*)segs, chunks);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

@@ -13,8 +13,12 @@ from .autograd import l1_loss, resize_aa
 
 
 def make_optimizer(model, lr: float = 1e-4):
-    """train.py:104 -- Adam, default betas/eps, no weight decay (parameters without grad are skipped)."""
-    return torch.optim.Adam(model.parameters(), lr=lr)
+    """train.py:104 -- Adam, default betas/eps, no weight decay (parameters without grad are skipped).  `optim.Adam` is
+    torch.optim.Adam with the whole update in one HIP launch; TUP_TORCH_ADAM=1 selects torch's own step."""
+    if os.environ.get("TUP_TORCH_ADAM"):
+        return torch.optim.Adam(model.parameters(), lr=lr)
+    from .optim import Adam
+    return Adam(model.parameters(), lr=lr)
 
 
 def train_step(model, optimizer, lr_batch: torch.Tensor, hr_batch: torch.Tensor) -> torch.Tensor:

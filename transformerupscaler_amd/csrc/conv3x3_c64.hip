@@ -463,6 +463,19 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 if (!ok) continue;
                 float* o = reinterpret_cast<float*>(out);
                 const int rr = r * r, cimg = cout_valid / rr, Hr = H * r, Wr = W * r;
+                if (CT == 1 && r == 2) {
+                    // PixelShuffle(2) of a lane's four outputs (channel g, sub-pixels e = 2 si + sj): the two sj of a row are
+                    // adjacent in the HR plane, so they go out as one 8-byte store (16 lanes = 128 contiguous bytes)
+                    if (g < cimg) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(acc[pg][0][e], 0.f) : acc[pg][0][e];
+                        float* base = o + (((size_t)b * cimg + g) * Hr + oy * 2) * Wr + ox * 2;
+                        *reinterpret_cast<f32x2*>(base) = f32x2{v[0], v[1]};
+                        *reinterpret_cast<f32x2*>(base + Wr) = f32x2{v[2], v[3]};
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll

@@ -61,5 +61,5 @@ def test_reducer_static_layout_is_backward_order():
     assert order.index("window_blocks.5.mlp.2.weight") < order.index("window_blocks.0.mlp.2.weight") < order.index("patch_embed.weight")
     assert len(red.bucket_ranges) == 3 and all(b > a for a, b in red.bucket_ranges)
     mixed = GradReducer(None, "cpu", scales=(2, 3, 4, 6))
-    assert mixed.mixed and mixed.flat.numel() > mixed.param_floats          # presence counts ride behind the parameters
-    assert mixed.bucket_ranges[-1][1] == mixed.flat.numel()
+    assert mixed.mixed and mixed.total_floats > mixed.param_floats          # presence counts ride behind the parameters
+    assert mixed.bucket_ranges[-1][1] == mixed.total_floats

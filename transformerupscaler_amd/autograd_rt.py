@@ -150,7 +150,7 @@ class _ResidualTransformerFn(torch.autograd.Function):
         outs = []
         for n in ctx.names:
             gr = grads.get(n)
-            outs.append(None if gr is None else gr.contiguous().clone() if reducer is not None else gr.contiguous())
+            outs.append(None if gr is None else gr.contiguous())      # reducer: views of this episode's own flat buffer (dp.py)
         return (None, None, None, None) + tuple(outs)
 
 

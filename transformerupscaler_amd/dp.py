@@ -97,7 +97,9 @@ class GradReducer:
         self.index = {n: i for i, n in enumerate(layout)}
         self.presence_off = cur                              # mixed layout: one float per parameter, reduced with the last bucket
         total = cur + ((len(layout) + 63) // 64 * 64 if self.mixed else 0)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.total_floats = total
+        self.flat = None          # allocated per backward episode: finish() hands out views of it, which stay valid (and may be
+                                  # accumulated into by train.py's per-sample loop) while the next episode fills a fresh buffer
         # buckets of >= bucket_mb in layout order
         bucket_elems = max(1, int(bucket_mb * (1 << 20) / 4))
         self.bucket_ranges: List[tuple] = []
@@ -145,12 +147,16 @@ class GradReducer:
             self._pending[self.bucket_of[n]] += 1
         self._next_bucket = 0
         self.launched_order = []
-        if len(act) != len(self.names):                      # segments this rank will not fill count as zeros in the sum
-            self.flat.zero_()
+        # segments this rank will not fill count as zeros in the sum; the alignment gaps between segments are reduced too but
+        # never read
+        alloc = torch.zeros if len(act) != len(self.names) else torch.empty
+        self.flat = alloc(self.total_floats, dtype=torch.float32, device=self.device)
+        if self.comm_stream is not None and dist.is_initialized():
+            self.flat.record_stream(self.comm_stream)        # the all-reduces run on the side stream
         if self.mixed:
             pres = self._presence_cache.get(act)
             if pres is None:
-                pres = torch.zeros(self.flat.numel() - self.presence_off, dtype=torch.float32)
+                pres = torch.zeros(self.total_floats - self.presence_off, dtype=torch.float32)
                 pres[[self.index[n] for n in act]] = 1.0
                 pres = self._presence_cache[act] = pres.to(self.device)
             self.flat[self.presence_off:].copy_(pres)
@@ -160,6 +166,7 @@ class GradReducer:
     def on_ready(self, names: List[str], grads: Dict[str, torch.Tensor]) -> None:
         if not self._in_step:
             self.begin(None)
+        dst, src = [], []
         for n in names:
             if n not in self.offset:
                 raise RuntimeError(f"gradient {n} is not in this reducer's layout (scale mismatch with DataParallel(scale=...))")
@@ -168,9 +175,14 @@ class GradReducer:
             if n in self._arrived:
                 raise RuntimeError(f"gradient {n} arrived twice in one backward")
             o = self.offset[n]
-            self.flat[o:o + self.numel[n]].copy_(grads[n].reshape(-1))
+            dst.append(self.flat[o:o + self.numel[n]].view(self.shapes[n]))
+            src.append(grads[n])
             self._arrived.add(n)
             self._pending[self.bucket_of[n]] -= 1
+        if len(dst) == 1:
+            dst[0].copy_(src[0])
+        elif dst:
+            torch._foreach_copy_(dst, src)                   # one launch per ready group (a block's 13 gradients) instead of 13
         self._advance()
 
     def _advance(self) -> None:

@@ -267,6 +267,14 @@ int tup_conv3x3_c64_wgrad_s2d(const void* x, const void* gmap, float* dwp, float
 int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga, float* tmp, const int* ystart, const int* yo,
                        const float* yw, const int* xstart, const int* xo, const float* xw, int planes, int Ha, int Wa,
                        int Ho, int Wo, void* stream);
+/* The same with the row pass in bands of 16 source rows (every output row is read once per band instead of once per source row it
+ * touches) and dense column tables: band_r0 / band_n int [ceil(Ha/16)] = first output row / row count of band b, band_w fp32
+ * [nbands][nr_max][16] = weight of output row band_r0[b] + i for source row 16 b + k (zero where none); xoT int / xwT fp32
+ * [kmax][Wa] = entry k of source column x's transposed tap list (padding: weight 0); blk_c0 / blk_n int [ceil(Wa/256)] = the
+ * stretch (<= 4096 columns) of a tmp row that source columns 256 j .. 256 j + 255 read. */
+int tup_rt_bicubic_bwd_banded(const float* gout, const float* out, float* ga, float* tmp, const int* band_r0, const int* band_n,
+                              const float* band_w, int nr_max, const int* xoT, const float* xwT, int kmax, const int* blk_c0,
+                              const int* blk_n, int planes, int Ha, int Wa, int Ho, int Wo, void* stream);
 
 /* ---- frame pre/post-processing either side of the model ---- */
 

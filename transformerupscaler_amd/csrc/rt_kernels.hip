@@ -508,17 +508,20 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
 // rows of either source, so the horizontal interpolation is done once per (source row, output column) into LDS and the
 // vertical one reads it back -- ~6 FMAs and LDS reads per output instead of 32 FMAs + 48 global loads.  Same fmaf chains
 // as the direct kernel, so the results are identical.
-constexpr int BIC_TR = 16, BIC_MAXROWS = 16;
+constexpr int BIC_TR = 16, BIC_MAXROWS = 16;           // BIC_TR: smallest tile height (rows); the launcher passes the largest that fits
 __global__ __launch_bounds__(256) void rt_bicubic_sum_sep_kernel(
     const float* __restrict__ a, const float* __restrict__ bsrc, float* __restrict__ out,
     const int* __restrict__ ayi, const float* __restrict__ ayw, const int* __restrict__ axi, const float* __restrict__ axw,
     const int* __restrict__ byi, const float* __restrict__ byw, const int* __restrict__ bxi, const float* __restrict__ bxw,
-    int Ha, int Wa, int Hb, int Wb, int Ho, int Wo, int clamp01)
+    int Ha, int Wa, int Hb, int Wb, int Ho, int Wo, int clamp01, int tr)
 {
-    __shared__ float hbuf[2][BIC_MAXROWS][64];
-    const int col = threadIdx.x & 63, rsub = threadIdx.x >> 6;
-    const int ox = blockIdx.x * 64 + col, oxc = min(ox, Wo - 1);
-    const int oy0 = blockIdx.y * BIC_TR, oy1 = min(oy0 + BIC_TR, Ho) - 1;
+    // one thread = one output column for all `tr` rows of the tile; the workgroup's 256 columns are adjacent, so its four waves
+    // store 1 KB of a row together (64-column tiles wrote 256-byte pieces 30 KB apart: 1.4 TB/s).  A thread reads back only its own
+    // column of the horizontally interpolated rows -- LDS serves as per-thread indexed storage, no barrier.
+    __shared__ float hbuf[2][BIC_MAXROWS][256];
+    const int col = threadIdx.x;
+    const int ox = blockIdx.x * 256 + col, oxc = min(ox, Wo - 1);
+    const int oy0 = blockIdx.y * tr, oy1 = min(oy0 + tr, Ho) - 1;
     const int plane = blockIdx.z;
     const float* pa = a + (size_t)plane * Ha * Wa;
     const float* pb = bsrc + (size_t)plane * Hb * Wb;
@@ -531,23 +534,22 @@ __global__ __launch_bounds__(256) void rt_bicubic_sum_sep_kernel(
         xa[j] = axi[oxc * 4 + j]; wa[j] = axw[oxc * 4 + j];
         xb[j] = bxi[oxc * 4 + j]; wb[j] = bxw[oxc * 4 + j];
     }
-    for (int r = rsub; r <= ya1 - ya0; r += 4) {
+    for (int r = 0; r <= ya1 - ya0; ++r) {
         const float* ra = pa + (size_t)(ya0 + r) * Wa;
         float h = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h = fmaf(wa[j], ra[xa[j]], h);
         hbuf[0][r][col] = h;
     }
-    for (int r = rsub; r <= yb1 - yb0; r += 4) {
+    for (int r = 0; r <= yb1 - yb0; ++r) {
         const float* rb = pb + (size_t)(yb0 + r) * Wb;
         float h = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) h = fmaf(wb[j], rb[xb[j]], h);
         hbuf[1][r][col] = h;
     }
-    __syncthreads();
     if (ox >= Wo) return;
-    for (int oy = oy0 + rsub; oy <= oy1; oy += 4) {
+    for (int oy = oy0; oy <= oy1; ++oy) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -573,26 +575,133 @@ __global__ __launch_bounds__(256) void rt_bicubic_bwd_rows_kernel(
     const float* gp = gout + (size_t)plane * Ho * Wo + ox;
     const float* op = out ? out + (size_t)plane * Ho * Wo + ox : nullptr;
     float acc = 0.f;
-    for (int t = t0; t < t1; ++t) {
-        const size_t off = (size_t)yo[t] * Wo;
-        float gv = gp[off];
-        if (op) { const float o = op[off]; gv = (o > 0.f && o < 1.f) ? gv : 0.f; }
-        acc += yw[t] * gv;
+    // four list entries per trip, every load of the trip requested before the first use (index clamped, weight zeroed past the
+    // end): the rolled loop paid one global round trip per entry (24 per output at x6)
+    for (int t = t0; t < t1; t += 4) {
+        float w[4], gv[4], ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int tt = min(t + u, t1 - 1);
+            w[u] = t + u < t1 ? yw[tt] : 0.f;
+            const size_t off = (size_t)yo[tt] * Wo;
+            gv[u] = gp[off];
+            ov[u] = op ? op[off] : 0.5f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += w[u] * ((ov[u] > 0.f && ov[u] < 1.f) ? gv[u] : 0.f);
     }
     tmp[((size_t)plane * Ha + y) * Wo + ox] = acc;
 }
 
+// Row pass in bands of BIC_YB source rows: the output rows a band touches are one contiguous range [r0, r0 + n), every one of
+// them is read ONCE (gradient + clamp gate) and feeds the band's BIC_YB accumulators through a dense, wave-uniform weight row
+// (scalar loads).  The per-source-row gather above reads every output row four times at x6 (6.4 GB of requests for 1.6 GB).
+constexpr int BIC_YB = 16;
+__global__ __launch_bounds__(256) void rt_bicubic_bwd_rows_band_kernel(
+    const float* __restrict__ gout, const float* __restrict__ out, float* __restrict__ tmp,
+    const int* __restrict__ band_r0, const int* __restrict__ band_n, const float* __restrict__ band_w, int nr_max,
+    int Ha, int Ho, int Wo)
+{
+    const int ox = blockIdx.x * 256 + threadIdx.x;
+    const int band = blockIdx.y, plane = blockIdx.z;
+    if (ox >= Wo) return;
+    const int r0 = band_r0[band], n = band_n[band];
+    const float* __restrict__ wrow = band_w + (size_t)band * nr_max * BIC_YB;
+    const float* gp = gout + ((size_t)plane * Ho + r0) * Wo + ox;
+    const float* op = out ? out + ((size_t)plane * Ho + r0) * Wo + ox : nullptr;
+    float acc[BIC_YB];
+#pragma unroll
+    for (int k = 0; k < BIC_YB; ++k) acc[k] = 0.f;
+    for (int i = 0; i < n; i += 4) {
+        float gv[4], ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t off = (size_t)min(i + u, n - 1) * Wo;
+            gv[u] = gp[off];
+            ov[u] = op ? op[off] : 0.5f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u >= n) break;                           // wave-uniform
+            const float g = (ov[u] > 0.f && ov[u] < 1.f) ? gv[u] : 0.f;
+#pragma unroll
+            for (int k = 0; k < BIC_YB; ++k) acc[k] = fmaf(wrow[(size_t)(i + u) * BIC_YB + k], g, acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BIC_YB; ++k) {
+        const int y = band * BIC_YB + k;
+        if (y < Ha) tmp[((size_t)plane * Ha + y) * Wo + ox] = acc[k];
+    }
+}
+
+// Column pass: 256 adjacent source columns per workgroup; the stretch of the tmp row their lists touch (a contiguous range, the
+// lists are monotone) is staged in LDS with coalesced loads, the per-column gathers then read LDS.  (Gathering straight from
+// global: 24 scattered 4-byte loads per output, 519 us for 22 MB of output.)
+constexpr int BIC_CSPAN = 4096;            // floats of LDS for the row stretch; wider stretches (ratios > ~15) use the direct form
 __global__ __launch_bounds__(256) void rt_bicubic_bwd_cols_kernel(
     const float* __restrict__ tmp, float* __restrict__ ga, const int* __restrict__ xstart, const int* __restrict__ xo,
     const float* __restrict__ xw, int Ha, int Wa, int Wo)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float seg[BIC_CSPAN];
+    const int x0 = blockIdx.x * 256, x = x0 + threadIdx.x;
     const int y = blockIdx.y, plane = blockIdx.z;
-    if (x >= Wa) return;
     const float* tp = tmp + ((size_t)plane * Ha + y) * Wo;
+    const int xl = min(x0 + 255, Wa - 1);
+    const int c0 = xo[xstart[x0]], c1 = xo[xstart[xl + 1] - 1];          // first / last output column of the workgroup's lists
+    const bool staged = c1 - c0 < BIC_CSPAN;
+    if (staged) {
+        for (int i = threadIdx.x; i <= c1 - c0; i += 256) seg[i] = tp[c0 + i];
+        __syncthreads();
+    }
+    if (x >= Wa) return;
     float acc = 0.f;
-    for (int t = xstart[x]; t < xstart[x + 1]; ++t) acc += xw[t] * tp[xo[t]];
+    const int t0 = xstart[x], t1 = xstart[x + 1];
+    for (int t = t0; t < t1; t += 8) {            // eight entries per trip, loads batched as in the row pass
+        float w[8], v[8];
+        int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int tt = min(t + u, t1 - 1);
+            w[u] = t + u < t1 ? xw[tt] : 0.f;
+            idx[u] = xo[tt];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = staged ? seg[idx[u] - c0] : tp[idx[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] * v[u];
+    }
     ga[((size_t)plane * Ha + y) * Wa + x] = acc;
+}
+
+// Column pass with dense per-column tap tables: xoT / xwT [kmax][Wa] (entry k of source column x; padded with weight 0), so a
+// thread's kmax index / weight loads are independent and coalesced across the workgroup (the CSR form above chains
+// xstart -> xo -> value: ~7 dependent round trips per workgroup); blk_c0 / blk_n = the stretch of the tmp row a workgroup stages.
+__global__ __launch_bounds__(256) void rt_bicubic_bwd_cols_dense_kernel(
+    const float* __restrict__ tmp, float* __restrict__ ga, const int* __restrict__ xoT, const float* __restrict__ xwT, int kmax,
+    const int* __restrict__ blk_c0, const int* __restrict__ blk_n, int Ha, int Wa, int Wo)
+{
+    __shared__ float seg[BIC_CSPAN];
+    const int x = blockIdx.x * 256 + threadIdx.x, xc = min(x, Wa - 1);
+    const int y = blockIdx.y, plane = blockIdx.z;
+    const float* tp = tmp + ((size_t)plane * Ha + y) * Wo;
+    const int c0 = blk_c0[blockIdx.x], n = blk_n[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 256) seg[i] = tp[c0 + i];
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < kmax; k += 8) {
+        float w[8];
+        int idx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = min(k + u, kmax - 1);
+            w[u] = k + u < kmax ? xwT[(size_t)kk * Wa + xc] : 0.f;
+            idx[u] = xoT[(size_t)kk * Wa + xc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += w[u] * seg[idx[u] - c0];
+    }
+    if (x < Wa) ga[((size_t)plane * Ha + y) * Wa + x] = acc;
 }
 
 }  // namespace
@@ -643,8 +752,14 @@ extern "C" int tup_rt_bicubic_sum_fwd(const float* a, const float* b, float* out
     // 16 output rows span at most 16/ratio + 4 source rows (the separable kernel's LDS tile holds 16).  Measured: at
     // ratio 6 / 12 (720p -> 8K) it is 1.9x faster than the direct kernel, at 1.5 / 3 (720p -> 1080p) 3x slower.
     if (Ho >= 3 * Ha && Ho >= 3 * Hb && (Ho + BIC_TR - 1) / BIC_TR <= 65535) {
-        dim3 grid((Wo + 63) / 64, (Ho + BIC_TR - 1) / BIC_TR, planes);
-        rt_bicubic_sum_sep_kernel<<<grid, dim3(256), 0, s>>>(a, b, out, ayi, ayw, axi, axw, byi, byw, bxi, bxw, Ha, Wa, Hb, Wb, Ho, Wo, clamp01);
+        // tile height: as many output rows as keep the source-row span (rows / ratio + 4 taps, + 1 for the phase) inside the LDS
+        // tile; at x6 that is 64 rows instead of 16 -- 194 k workgroups of ~4 outputs per thread were launch-bound (797 us for
+        // 796 MB written)
+        const int hmax = Ha > Hb ? Ha : Hb;
+        int tr = BIC_TR;
+        while (tr + 4 <= 64 && (long long)(tr + 4) * hmax / Ho + 5 <= BIC_MAXROWS) tr += 4;
+        dim3 grid((Wo + 255) / 256, (Ho + tr - 1) / tr, planes);
+        rt_bicubic_sum_sep_kernel<<<grid, dim3(256), 0, s>>>(a, b, out, ayi, ayw, axi, axw, byi, byw, bxi, bxw, Ha, Wa, Hb, Wb, Ho, Wo, clamp01, tr);
         TUP_CHECK_LAUNCH();
         return 0;
     }
@@ -702,3 +817,27 @@ extern "C" int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga
     TUP_CHECK_LAUNCH();
     return 0;
 }
+
+// tup_rt_bicubic_bwd with the row pass in bands of 16 source rows (rt_bicubic_bwd_rows_band_kernel) and dense column tables:
+// band_r0 / band_n int [nbands] = first output row and row count of band b (source rows 16b .. 16b+15), band_w fp32
+// [nbands][nr_max][16] = weight of output row r0 + i for source row 16b + k (zero where none; rows i >= n are not read);
+// xoT int / xwT fp32 [kmax][Wa] = entry k of source column x's transposed tap list (padded: weight 0, any in-range index),
+// blk_c0 / blk_n int [ceil(Wa/256)] = first tmp column and count (<= 4096) the lists of source columns 256j .. 256j+255 touch.
+// Same results up to the order of the fp32 sums.
+extern "C" int tup_rt_bicubic_bwd_banded(const float* gout, const float* out, float* ga, float* tmp, const int* band_r0,
+                                         const int* band_n, const float* band_w, int nr_max, const int* xoT, const float* xwT,
+                                         int kmax, const int* blk_c0, const int* blk_n, int planes, int Ha, int Wa, int Ho, int Wo,
+                                         void* stream)
+{
+    if (planes <= 0) return 0;
+    const int nbands = (Ha + BIC_YB - 1) / BIC_YB;
+    if (planes > 65535 || Ha > 65535 || nbands > 65535 || nr_max < 1 || kmax < 1) return (int)hipErrorInvalidValue;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rt_bicubic_bwd_rows_band_kernel<<<dim3((Wo + 255) / 256, nbands, planes), dim3(256), 0, s>>>(
+        gout, out, tmp, band_r0, band_n, band_w, nr_max, Ha, Ho, Wo);
+    TUP_CHECK_LAUNCH();
+    rt_bicubic_bwd_cols_dense_kernel<<<dim3((Wa + 255) / 256, Ha, planes), dim3(256), 0, s>>>(tmp, ga, xoT, xwT, kmax, blk_c0, blk_n, Ha, Wa, Wo);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+

@@ -701,15 +701,84 @@ def _bicubic_t_on(device, in_size, out_size):
     return _BICT_CACHE[key]
 
 
+_BICB_CACHE = {}
+_BIC_YB = 16
+bicubic_bwd_banded = not os.environ.get("TUP_BICUBIC_BWD_GATHER")        # A/B switch: per-source-row gather of the row pass
+
+
+def _bicubic_bands_on(device, in_size, out_size):
+    """Band tables of the row pass of rt_bicubic_bwd: for source rows 16b .. 16b+15 the contiguous range of output rows that touch
+    them and the dense weights [rows][16] (transpose of the forward tap matrix)."""
+    key = (str(device), in_size, out_size)
+    if key not in _BICB_CACHE:
+        import numpy as np
+        from .resize_taps import bicubic_taps
+        idx, w = bicubic_taps(in_size, out_size)             # [out][4]
+        nb = (in_size + _BIC_YB - 1) // _BIC_YB
+        lo = np.full(in_size, out_size, dtype=np.int64); hi = np.full(in_size, -1, dtype=np.int64)
+        for k in range(4):
+            np.minimum.at(lo, idx[:, k], np.arange(out_size)); np.maximum.at(hi, idx[:, k], np.arange(out_size))
+        r0 = np.array([lo[b * _BIC_YB:(b + 1) * _BIC_YB].min() for b in range(nb)], dtype=np.int64)
+        r1 = np.array([hi[b * _BIC_YB:(b + 1) * _BIC_YB].max() for b in range(nb)], dtype=np.int64)
+        n = (r1 - r0 + 1).clip(min=1)
+        r0 = np.minimum(r0, out_size - 1)
+        nr_max = int(n.max())
+        bw = np.zeros((nb, nr_max, _BIC_YB), dtype=np.float32)
+        rows = np.arange(out_size)
+        for k in range(4):
+            y = idx[:, k]; b = y // _BIC_YB
+            np.add.at(bw, (b, rows - r0[b], y - b * _BIC_YB), w[:, k].astype(np.float32))
+        _BICB_CACHE[key] = (torch.from_numpy(r0.astype(np.int32)).to(device), torch.from_numpy(n.astype(np.int32)).to(device),
+                            torch.from_numpy(bw).to(device), nr_max)
+    return _BICB_CACHE[key]
+
+
+_BICC_CACHE = {}
+
+
+def _bicubic_cols_on(device, in_size, out_size):
+    """Dense column tables of rt_bicubic_bwd: (xoT int32 [kmax][in], xwT fp32 [kmax][in], kmax, blk_c0, blk_n) from the transposed
+    tap lists; None when a 256-column block's stretch exceeds the kernel's LDS tile (very large ratios)."""
+    key = (str(device), in_size, out_size)
+    if key not in _BICC_CACHE:
+        import numpy as np
+        from .resize_taps import bicubic_taps, transpose_taps
+        idx, w = bicubic_taps(in_size, out_size)
+        xs, xo, xw = transpose_taps(idx, w, in_size)
+        cnt = np.diff(xs)
+        kmax = int(cnt.max())
+        xoT = np.zeros((kmax, in_size), dtype=np.int32); xwT = np.zeros((kmax, in_size), dtype=np.float32)
+        for x in range(in_size):
+            n = cnt[x]
+            xoT[:n, x] = xo[xs[x]:xs[x] + n]; xwT[:n, x] = xw[xs[x]:xs[x] + n]
+            xoT[n:, x] = xo[xs[x]]                                  # padding: in-range index, weight 0
+        nblk = (in_size + 255) // 256
+        c0 = np.array([xoT[:, j * 256:(j + 1) * 256].min() for j in range(nblk)], dtype=np.int32)
+        c1 = np.array([xoT[:, j * 256:(j + 1) * 256].max() for j in range(nblk)], dtype=np.int32)
+        nn = c1 - c0 + 1
+        _BICC_CACHE[key] = None if int(nn.max()) > 4096 else (
+            torch.from_numpy(xoT).to(device), torch.from_numpy(xwT).to(device), kmax, torch.from_numpy(c0).to(device),
+            torch.from_numpy(nn.astype(np.int32)).to(device))
+    return _BICC_CACHE[key]
+
+
 def rt_bicubic_bwd(gout, out, in_hw):
     """Gradient of clamp(bicubic(src -> size) + ...) w.r.t. a planar fp32 source of size in_hw; `out` = the saved
     forward output (the clamp gate) or None."""
     B, C, Ho, Wo = gout.shape
     Ha, Wa = in_hw
-    ys, yo, yw = _bicubic_t_on(gout.device, Ha, Ho)
-    xs, xo, xw = _bicubic_t_on(gout.device, Wa, Wo)
     ga = torch.empty((B, C, Ha, Wa), dtype=F32, device=gout.device)
     tmp = torch.empty((B, C, Ha, Wo), dtype=F32, device=gout.device)
+    cols = _bicubic_cols_on(gout.device, Wa, Wo) if bicubic_bwd_banded else None
+    if cols is not None:
+        r0, bn, bw, nr_max = _bicubic_bands_on(gout.device, Ha, Ho)
+        xoT, xwT, kmax, c0, cn = cols
+        _lib.call("tup_rt_bicubic_bwd_banded", _chk(gout, F32, None, "gout"), _opt(out, F32, (B, C, Ho, Wo), "out"), ga.data_ptr(),
+                  tmp.data_ptr(), r0.data_ptr(), bn.data_ptr(), bw.data_ptr(), nr_max, xoT.data_ptr(), xwT.data_ptr(), kmax,
+                  c0.data_ptr(), cn.data_ptr(), B * C, Ha, Wa, Ho, Wo, _stream())
+        return ga
+    xs, xo, xw = _bicubic_t_on(gout.device, Wa, Wo)
+    ys, yo, yw = _bicubic_t_on(gout.device, Ha, Ho)
     _lib.call("tup_rt_bicubic_bwd", _chk(gout, F32, None, "gout"), _opt(out, F32, (B, C, Ho, Wo), "out"), ga.data_ptr(), tmp.data_ptr(),
               ys.data_ptr(), yo.data_ptr(), yw.data_ptr(), xs.data_ptr(), xo.data_ptr(), xw.data_ptr(), B * C, Ha, Wa, Ho, Wo, _stream())
     return ga

@@ -607,6 +607,64 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_kernel(
     gin[((size_t)plane * Hi + y) * Wi + x] = acc;
 }
 
+// Separable form of the above: a workgroup owns RB_TR input rows x 256 input columns, a thread one column.  Horizontal pass: for
+// every output row the tile's input rows reference, t[oy] = sum over the column's outputs of wx * (gated) gout -- once per
+// (output row, column), into LDS (read back by the same thread only); vertical pass: gin[y] = sum_oy wy * t[oy].
+constexpr int RB_TR = 16, RB_MAXR = 32;
+__global__ __launch_bounds__(256) void resize_aa_bwd_sep_kernel(
+    const float* __restrict__ gout, const float* __restrict__ pre, float* __restrict__ gin,
+    const int* __restrict__ ymin, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
+    const float* __restrict__ xw, int KX, const int* __restrict__ oy0, const int* __restrict__ oyn,
+    const int* __restrict__ ox0, const int* __restrict__ oxn, int Hi, int Wi, int Ho, int Wo)
+{
+    __shared__ float tbuf[RB_MAXR][256];
+    const int col = threadIdx.x;
+    const int x = blockIdx.x * 256 + col, xc = min(x, Wi - 1);
+    const int ya = blockIdx.y * RB_TR, yb = min(ya + RB_TR, Hi) - 1;
+    const int plane = blockIdx.z;
+    const float* go = gout + (size_t)plane * Ho * Wo;
+    const float* pr = pre ? pre + (size_t)plane * Ho * Wo : nullptr;
+    // output rows referenced by input rows ya..yb: the per-row ranges are monotone in y
+    int o0 = Ho, o1 = -1;
+    for (int y = ya; y <= yb; ++y) {
+        const int a = oy0[y], n = oyn[y];
+        if (n > 0) { o0 = min(o0, a); o1 = max(o1, a + n - 1); }
+    }
+    const int xa = ox0[xc], xn = oxn[xc];
+    constexpr int XN = 6;                        // outputs referencing one input column (host checks the bound)
+    float wx[XN];
+#pragma unroll
+    for (int j = 0; j < XN; ++j) { const int ox = min(xa + j, Wo - 1); wx[j] = j < xn ? xw[ox * KX + (xc - xmin[ox])] : 0.f; }
+    for (int oy = o0; oy <= o1; oy += 4) {       // four output rows per trip, all their loads in flight together
+        float gv[4][XN], pv[4][XN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < XN; ++j) {
+                const size_t o = (size_t)min(oy + u, o1) * Wo + min(xa + j, Wo - 1);
+                gv[u][j] = j < xn ? go[o] : 0.f;
+                pv[u][j] = (pr && j < xn) ? pr[o] : 0.5f;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float h = 0.f;
+#pragma unroll
+            for (int j = 0; j < XN; ++j) h = fmaf(wx[j], (pv[u][j] >= 0.f && pv[u][j] <= 1.f) ? gv[u][j] : 0.f, h);
+            if (oy + u <= o1) tbuf[oy + u - o0][col] = h;
+        }
+    }
+    if (x >= Wi) return;
+    for (int y = ya; y <= yb; ++y) {
+        const int a = oy0[y], n = oyn[y];
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) {
+            const int oy = a + i;
+            acc = fmaf(yw[oy * KY + (y - ymin[oy])], tbuf[oy - o0][col], acc);
+        }
+        gin[((size_t)plane * Hi + y) * Wi + x] = acc;
+    }
+}
+
 // gin = gout * (0 <= pre <= 1) [* (relu_src > 0)]
 __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                        const float* __restrict__ relu_src, float* __restrict__ gin, size_t n)
@@ -777,6 +835,15 @@ extern "C" int tup_resize_aa_bwd(const float* gout, const float* pre, float* gin
 {
     if (planes <= 0) return 0;
     if (planes > 65535) return (int)hipErrorInvalidValue;
+    // separable kernel when a column is referenced by <= 6 outputs (an output reads KX adjacent columns, so an input column feeds at
+    // most KX * Wo / Wi + 2 outputs) and RB_TR input rows never reference more than RB_MAXR output rows
+    static const bool gather = getenv("TUP_RESIZE_GATHER") != nullptr;             // A/B switch
+    if (!gather && (long long)KX * Wo / Wi + 2 <= 6 && (long long)RB_TR * Ho / Hi + KY + 2 <= RB_MAXR) {
+        resize_aa_bwd_sep_kernel<<<dim3((Wi + 255) / 256, (Hi + RB_TR - 1) / RB_TR, planes), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+            gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((Wi + 63) / 64, (Hi + 3) / 4, planes);
     resize_aa_bwd_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo);

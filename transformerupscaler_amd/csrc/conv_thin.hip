@@ -349,6 +349,55 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(
     out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
 }
 
+// Separable form: a workgroup owns RS_TR output rows x 256 output columns, a thread one column.  The horizontal taps are applied
+// once per (input row of the tile, column) into LDS (read back by the same thread only: per-thread indexed storage, no barrier),
+// the vertical taps read it: ~(rows/ratio + KY) * nx + ny loads per RS_TR outputs instead of ny * 8 per output, and the four waves
+// store 1 KB of an output row together.  Same fmaf chains per axis as the 2-D gather above, but the horizontal sum is formed before
+// the vertical one for every input row (the gather does the same) -- identical results.  RS_MAXR bounds the input-row span.
+constexpr int RS_TR = 16, RS_MAXR = 32;
+__global__ __launch_bounds__(256) void resize_aa_sep_kernel(
+    const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ ymin,
+    const int* __restrict__ ysize, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
+    const int* __restrict__ xsize, const float* __restrict__ xw, int KX, int Hi, int Wi, int Ho, int Wo,
+    int clamp01)
+{
+    __shared__ float hbuf[RS_MAXR][256];
+    const int col = threadIdx.x;
+    const int ox = blockIdx.x * 256 + col, oxc = min(ox, Wo - 1);
+    const int oy0 = blockIdx.y * RS_TR, oy1 = min(oy0 + RS_TR, Ho) - 1;
+    const int plane = blockIdx.z;
+    const float* src = in + (size_t)plane * Hi * Wi;
+    const int r0 = ymin[oy0], r1 = ymin[oy1] + ysize[oy1] - 1;          // monotone tables: input rows of the tile
+    const int x0 = xmin[oxc], nx = xsize[oxc];
+    float wx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wx[j] = j < nx ? xw[oxc * KX + j] : 0.f;
+    for (int r = r0; r <= r1; r += 4) {          // four input rows per trip, all their loads in flight together
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* rowp = src + (size_t)min(r + u, r1) * Wi + x0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] = j < nx ? rowp[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float h = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h = fmaf(wx[j], v[u][j], h);
+            if (r + u <= r1) hbuf[r + u - r0][col] = h;
+        }
+    }
+    if (ox >= Wo) return;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        const int y0 = ymin[oy] - r0, ny = ysize[oy];
+        float acc = 0.f;
+        for (int i = 0; i < ny; ++i) acc = fmaf(yw[oy * KY + i], hbuf[y0 + i][col], acc);
+        if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+        out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void clamp01_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n)
 {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -404,6 +453,15 @@ extern "C" int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, c
 {
     if (planes <= 0) return 0;
     if (planes > 65535) return (int)hipErrorInvalidValue;
+    // separable kernel when every column has <= 8 taps and RS_TR output rows never span more than RS_MAXR input rows
+    // (RS_TR / ratio + KY + 1 is an upper bound of the span)
+    static const bool gather = getenv("TUP_RESIZE_GATHER") != nullptr;             // A/B switch
+    if (!gather && KX <= 8 && (long long)RS_TR * Hi / Ho + KY + 2 <= RS_MAXR) {
+        resize_aa_sep_kernel<<<dim3((Wo + 255) / 256, (Ho + RS_TR - 1) / RS_TR, planes), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+            in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, planes);
     resize_aa_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01);

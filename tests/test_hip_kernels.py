@@ -88,6 +88,21 @@ def test_conv_planar(dev, r):
     close(got, (ref + add).clamp(0, 1), 2e-6, 1e-5, "planar conv + add + clamp")
 
 
+@pytest.mark.parametrize("hw", [(23, 72), (5, 4), (9, 260), (33, 1024)])
+def test_conv_planar_r1_four_pixels_per_thread(dev, hw):
+    """The r = 1, W % 4 == 0 kernel (four pixels per thread, final_upscale_conv at HR and its input gradient) against torch: image
+    borders, widths that are not a multiple of the 256-pixel block, a single 4-pixel column; with and without add + clamp."""
+    from transformerupscaler_amd import ops, packing
+    x = rnd((2, 3) + hw, 20)
+    w, b = rnd((3, 3, 3, 3), 21, 0.3), rnd((3,), 22, 0.2)
+    ref = F.conv2d(x, w, b, padding=1)
+    close(ops.conv_planar(x.to(dev), packing.pack_planar(w).to(dev), b.to(dev), 1), ref, 2e-6, 1e-5, "planar conv r1x4")
+    close(ops.conv_planar(x.to(dev), packing.pack_planar(w).to(dev), None, 1), F.conv2d(x, w, None, padding=1), 2e-6, 1e-5, "no bias")
+    add = rnd(tuple(ref.shape), 23)
+    got = ops.conv_planar(x.to(dev), packing.pack_planar(w).to(dev), b.to(dev), 1, add=add.to(dev), clamp=True)
+    close(got, (ref + add).clamp(0, 1), 2e-6, 1e-5, "planar conv r1x4 + add + clamp")
+
+
 @pytest.mark.parametrize("sizes", [((72, 96), (54, 72)), ((64, 64), (48, 48)), ((30, 40), (45, 47)), ((144, 256), (108, 192))])
 def test_resize_aa(dev, sizes):
     from transformerupscaler_amd import ops

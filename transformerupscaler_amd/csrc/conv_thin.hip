@@ -305,6 +305,78 @@ __global__ __launch_bounds__(256) void conv3x3_planar_kernel(
     }
 }
 
+// The r = 1, 3 -> 3 case (final_upscale_conv at HR and its input gradient, model.py:317): FOUR adjacent pixels per thread.  A row of
+// a thread's 3x6 input window is one aligned 16-byte load + two edge scalars, so the four pixels cost 27 load instructions instead
+// of 108 and the 81 weights sit in registers.  W % 4 == 0.
+__global__ __launch_bounds__(256) void conv3x3_planar_r1x4_kernel(
+    const float* __restrict__ x, const float* __restrict__ w28, const float* __restrict__ bias,
+    const float* __restrict__ add, float* __restrict__ out, int H, int W, int clamp01)
+{
+    __shared__ __attribute__((aligned(16))) float wl[3 * 28 + 4];
+    if (threadIdx.x < 84) wl[threadIdx.x] = w28[threadIdx.x];
+    if (threadIdx.x < 3) wl[84 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    float wr[3][27];
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const f32x4 wq = *reinterpret_cast<const f32x4*>(wl + co * 28 + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q * 4 + e < 27) wr[co][q * 4 + e] = wq[e];
+        }
+    f32x4 acc[3];
+#pragma unroll
+    for (int co = 0; co < 3; ++co) acc[co] = f32x4{wl[84 + co], wl[84 + co], wl[84 + co], wl[84 + co]};
+    // all 27 loads of the thread are requested before the first use
+    f32x4 m[3][3];
+    float e0[3][3], e5[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy + dy - 1;
+            const bool in = iy >= 0 && iy < H;                 // wave-uniform (a wave is one output row)
+            const float* row = x + (((size_t)b * 3 + c) * H + (in ? iy : oy)) * W;
+            m[c][dy] = *reinterpret_cast<const f32x4*>(row + ox);
+            e0[c][dy] = row[ox > 0 ? ox - 1 : ox];
+            e5[c][dy] = row[ox + 4 < W ? ox + 4 : ox];
+            if (!in) { m[c][dy] = f32x4{0.f, 0.f, 0.f, 0.f}; e0[c][dy] = 0.f; e5[c][dy] = 0.f; }
+            if (ox == 0) e0[c][dy] = 0.f;
+            if (ox + 4 >= W) e5[c][dy] = 0.f;
+        }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const float v[6] = {e0[c][dy], m[c][dy][0], m[c][dy][1], m[c][dy][2], m[c][dy][3], e5[c][dy]};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int co = 0; co < 3; ++co) {
+                    const float wk = wr[co][c * 9 + dy * 3 + dx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[co][e] = fmaf(wk, v[e + dx], acc[co][e]);
+                }
+        }
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+        const size_t oi = (((size_t)b * 3 + co) * H + oy) * W + ox;
+        f32x4 s = acc[co];
+        if (add) s += *reinterpret_cast<const f32x4*>(add + oi);
+        if (clamp01) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] = fminf(fmaxf(s[e], 0.f), 1.f);
+        }
+        *reinterpret_cast<f32x4*>(out + oi) = s;
+    }
+}
+
 // Separable antialiased-bilinear resize evaluated as one 2-D gather per output pixel.
 // Tap tables (ymin/ysize/yw[Ho][KY], xmin/xsize/xw[Wo][KX]) are built on the host exactly as
 // aten's _compute_indices_weights_aa does (float32); see transformerupscaler_amd/resize_taps.py.
@@ -440,6 +512,13 @@ extern "C" int tup_conv3x3_planar_fwd(const float* x, const float* w28, const fl
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     if (r < 1 || r > 6 || B > 65535) return (int)hipErrorInvalidValue;
     const int cout = 3 * r * r;
+    static const bool one_px = getenv("TUP_PLANAR_ONE_PIXEL") != nullptr;           // A/B switch
+    if (r == 1 && W % 4 == 0 && !one_px) {
+        conv3x3_planar_r1x4_kernel<<<dim3((W / 4 + 63) / 64, (H + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+            x, w28, bias, add, out, H, W, clamp01);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((W + 63) / 64, (H + 3) / 4, B);
     conv3x3_planar_kernel<<<grid, dim3(256), (size_t)cout * 29 * sizeof(float),
                             reinterpret_cast<hipStream_t>(stream)>>>(x, w28, bias, add, out, H, W, r, clamp01);

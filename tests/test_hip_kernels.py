@@ -377,6 +377,19 @@ def test_conv_planar_backward(dev, r):
         close(ops.conv_planar(gy.to(dev), packing.pack_planar_dgrad(w.detach()).to(dev), None, 1), x.grad, 1e-5, 1e-5, "planar dgrad via fwd kernel")
 
 
+@pytest.mark.parametrize("hw", [(23, 72), (5, 4), (9, 260), (33, 512)])
+def test_conv_planar_dgrad_r2_four_pixels_per_thread(dev, hw):
+    """The r = 2, W % 4 == 0 input-gradient kernel (four LR pixels per thread) against torch autograd through conv + PixelShuffle:
+    image borders, one 4-pixel column, widths that are not a multiple of the 256-pixel block."""
+    from transformerupscaler_amd import ops
+    x = rnd((2, 3) + hw, 80).requires_grad_(True)
+    w = rnd((12, 3, 3, 3), 81, 0.3)
+    y = F.pixel_shuffle(F.conv2d(x, w, None, padding=1), 2)
+    gy = rnd(tuple(y.shape), 82)
+    y.backward(gy)
+    close(ops.conv_planar_dgrad(gy.to(dev), w.to(dev), 2), x.grad, 1e-5, 1e-5, "planar dgrad r2x4")
+
+
 @pytest.mark.parametrize("sizes", [((72, 96), (54, 72)), ((30, 40), (45, 47)), ((144, 256), (108, 192))])
 def test_resize_and_clamp_backward(dev, sizes):
     from transformerupscaler_amd import ops

@@ -551,6 +551,62 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_planar_kernel(
     gx[o] = a0; gx[o + (size_t)H * W] = a1; gx[o + 2 * (size_t)H * W] = a2;
 }
 
+// The r = 2 case of the above (the last final_upscale stage at every scale but 3; model.py:316): FOUR adjacent LR pixels per thread.
+// The 6 HR rows x 12 HR columns the four pixels gather from are four aligned 16-byte loads per row (72 loads per thread instead
+// of 432 two-element-strided ones); every HR value feeds up to three of the four outputs, all with wave-uniform weights (scalar
+// loads from the weight tensor: the indices are compile-time constants).  W % 4 == 0.
+__global__ __launch_bounds__(256) void conv3x3_dgrad_planar_r2x4_kernel(
+    const float* __restrict__ gpl, const float* __restrict__ w, float* __restrict__ gx, int H, int W)
+{
+    const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (ox >= W || oy >= H) return;
+    const int Hr = 2 * H, Wr = 2 * W;
+    f32x4 acc[3];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) acc[ci] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool lft = ox > 0, rgt = ox + 4 < W;                   // the first / last 16-byte piece of a row is inside the image
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* gp = gpl + ((size_t)b * 3 + c) * Hr * Wr;
+        f32x4 v[6][4];
+#pragma unroll
+        for (int ry = 0; ry < 6; ++ry) {
+            const int Y = 2 * (oy - 1) + ry;
+            const bool in = Y >= 0 && Y < Hr;                    // wave-uniform (a wave is one LR row)
+            const float* row = gp + (size_t)(in ? Y : 0) * Wr + 2 * ox;
+            v[ry][0] = *reinterpret_cast<const f32x4*>(row + (lft ? -4 : 0));
+            v[ry][1] = *reinterpret_cast<const f32x4*>(row);
+            v[ry][2] = *reinterpret_cast<const f32x4*>(row + 4);
+            v[ry][3] = *reinterpret_cast<const f32x4*>(row + (rgt ? 8 : 4));
+            if (!in) { v[ry][1] = f32x4{0.f, 0.f, 0.f, 0.f}; v[ry][2] = v[ry][1]; }
+            if (!in || !lft) v[ry][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!in || !rgt) v[ry][3] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ry = 0; ry < 6; ++ry) {
+            const int si = ry & 1, ky = 2 - (ry >> 1);            // HR row 2 (oy - 1 + ry / 2) + si  <->  tap row ky
+#pragma unroll
+            for (int i = 2; i < 14; ++i) {                        // HR column 2 ox - 4 + i = 2 (ox + xr) + sj
+                const int sj = i & 1, xr = (i >> 1) - 2;
+                const float g = v[ry][i >> 2][i & 3];
+                const float* wc = w + (c * 4 + si * 2 + sj) * 27 + ky * 3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kx = e + 1 - xr;                    // output ox + e reads LR column ox + e + 1 - kx
+                    if (kx < 0 || kx > 2) continue;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) acc[ci][e] = fmaf(wc[ci * 9 + kx], g, acc[ci][e]);
+                }
+            }
+        }
+    }
+    const size_t o = ((size_t)b * 3 * H + oy) * W + ox;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) *reinterpret_cast<f32x4*>(gx + o + (size_t)ci * H * W) = acc[ci];
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward of (antialiased resize -> clamp): gin[y][x] = sum over the output pixels whose taps cover
 // (y, x) of wy*wx*gout, gout masked by 0 <= pre <= 1 when `pre` (the pre-clamp output) is given.
@@ -821,6 +877,12 @@ extern "C" int tup_conv3x3_planar_dgrad(const float* gpl, const float* w, float*
 {
     if (B <= 0) return 0;
     if (r < 1 || r > 6 || B > 65535) return (int)hipErrorInvalidValue;
+    static const bool one_px = getenv("TUP_PLANAR_ONE_PIXEL") != nullptr;           // A/B switch
+    if (r == 2 && W % 4 == 0 && !one_px) {
+        conv3x3_dgrad_planar_r2x4_kernel<<<dim3((W / 4 + 63) / 64, (H + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(gpl, w, gx, H, W);
+        TUP_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((W + 63) / 64, (H + 3) / 4, B);
     conv3x3_dgrad_planar_kernel<<<grid, dim3(256), (size_t)3 * r * r * 27 * sizeof(float), reinterpret_cast<hipStream_t>(stream)>>>(
         gpl, w, gx, H, W, r);

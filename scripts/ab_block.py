@@ -15,14 +15,23 @@ x0 = raw["x"].to("cuda")
 arr, nblk, keep = ops.block_table([tuple(args)] * 6)
 P, I = ctypes.c_void_p, ctypes.c_int
 runs = {}
+wh_perm = args[2]                                   # as packing.pack_qkv_heads packs it now (K columns in accumulator order)
+wh_nat = ops._wh_natural_k(wh_perm)                 # libraries built before that change: name=path@natural
+keep = [keep]
 for name, path in libs.items():
+    path, _, flag = path.partition("@")
+    natural = flag == "natural"
     L = ctypes.CDLL(os.path.join(root, path))
     L.tup_fused_block_fwd.argtypes = [P] * 14 + [I, P]
     ptrs = [a.data_ptr() for a in args]
+    if natural:
+        ptrs[2] = wh_nat.data_ptr()
     runs[name + "/6 launches"] = (lambda x, L=L, ptrs=ptrs: [L.tup_fused_block_fwd(x.data_ptr(), *ptrs, nwin, None) for _ in range(6)])
     if hasattr(L, "tup_fused_blocks32_fwd"):
         L.tup_fused_blocks32_fwd.argtypes = [P, P, I, I, P]
-        runs[name + "/1 launch"] = (lambda x, L=L: L.tup_fused_blocks32_fwd(x.data_ptr(), arr, 6, nwin, None))
+        tab = ops.block_table([tuple(args[:2]) + (wh_nat if natural else wh_perm,) + tuple(args[3:])] * 6)
+        keep.append(tab)
+        runs[name + "/1 launch"] = (lambda x, L=L, tab=tab: L.tup_fused_blocks32_fwd(x.data_ptr(), tab[0], 6, nwin, None))
 x = x0.clone()
 ref = None
 for k, f in runs.items():

@@ -14,6 +14,7 @@ raw, args = T._block_operands(dev, nwin)
 x0 = raw["x"].to(dev)
 variants = {"block32": 32, "blocks32x6": -1, "block64": 64, "blocks64x6": 0}
 table6 = ops.block_table([tuple(args)] * 6)
+table6_64 = ops.block_table([tuple(args)] * 6, natural_k=True)
 xs = {k: x0.clone() for k in variants}
 times = {k: [] for k in variants}
 for k, tpw in variants.items():                       # warm-up
@@ -28,7 +29,7 @@ for r in range(rounds):
         if tpw == -1:
             ops.fused_blocks32(xs[k], table6)
         elif tpw == 0:
-            ops.fused_blocks64(xs[k], table6)          # the 6 blocks of a forward in one launch
+            ops.fused_blocks64(xs[k], table6_64)          # the 6 blocks of a forward in one launch
         else:
             for _ in range(6):                            # ... as 6 launches
                 ops.fused_block(xs[k], *args, tokens_per_wave=tpw)

@@ -624,14 +624,20 @@ def test_blocks64_six_in_one_launch_equals_six_launches(dev):
     ops_ = [_block_operands(dev, nwin, seed=40 + i)[1] for i in range(3)]
     x = _block_operands(dev, nwin, seed=50)[0]["x"].to(dev)
     seq = [ops_[i % 3] for i in range(6)]
-    one = ops.fused_blocks64(x.clone(), ops.block_table([tuple(a) for a in seq]))
+    one = ops.fused_blocks64(x.clone(), ops.block_table([tuple(a) for a in seq], natural_k=True))
     ref = x.clone()
     for a in seq:
         ops.fused_block(ref, *a, tokens_per_wave=64)
     assert torch.isfinite(one).all()
     assert torch.equal(one, ref)
+    # the default kernel: six blocks in one launch (x carried in registers between blocks) == six single-block launches, bit for
+    # bit; against the one-wave kernel it differs only by the summation order inside LayerNorm1
     one32 = ops.fused_blocks32(x.clone(), ops.block_table([tuple(a) for a in seq]))
-    assert torch.equal(one32, ref)                    # the default kernel in one launch: the same bits again
+    ref32 = x.clone()
+    for a in seq:
+        ops.fused_block(ref32, *a, tokens_per_wave=32)
+    assert torch.equal(one32, ref32)
+    assert (one32 - ref).abs().max().item() <= 1e-2 * max(1.0, ref.abs().max().item())      # six blocks of bf16 rounding flips
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 8, 32), (1, 13, 37), (2, 24, 70), (1, 6, 6)])

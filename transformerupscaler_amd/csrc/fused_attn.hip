@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     // block, model.py:283-289), so this workgroup carries its two windows through all of them; between blocks x passes through
     // memory as the waves' own stores followed by their own loads (served by L2), the chip-wide load / store bursts of a launch
     // boundary and the boundary itself disappear
+    // the residual stream of this wave's 32 tokens in the layout of the proj / FC2 accumulators (lane (g, pl): token 16 tg + pl,
+    // channels (n >> 2) * 64 + 16 g + (n & 3) * 4 .. +3 for n < 12).  LayerNorm1 reads it in THIS layout (the qkv weight's K columns
+    // are packed to match, packing.pack_qkv_heads, as mlp.0's are for LayerNorm2), so from the second block of a launch on it
+    // is the previous block's accumulators: no load, the stream only goes out to memory (for the residual re-read at the proj)
+    f32x4 xcar[2][12];
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
     // the thread's coordinates are recomputed per block from an opaque copy of threadIdx: as loop invariants hipcc hoists the
@@ -154,45 +159,41 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     dma_w(0, 0);
     dma_w(1, 1);
 
-    // ---- LayerNorm1 straight into B fragments: token 16tg+pl, channels 32*st + 8g .. +8 ----
-    // all 48 loads (the wave's x rows, gamma, beta) stand together in program order, ahead of the arithmetic: written per row as
-    // load-then-use, hipcc under register pressure emits one global round trip per pair of loads
+    // ---- LayerNorm1 straight into B fragments.  K-step st of the qkv product contracts over channels
+    // 64 (st >> 1) + 16 g + 8 (st & 1) .. +8 = the lane's residual values n = 2 st, 2 st + 1 ----
+    // the loads (the wave's x rows in the first block of a launch, gamma, beta) stand together in program order, ahead of the
+    // arithmetic: written per row as load-then-use, hipcc under register pressure emits one global round trip per pair of loads
     bf16x8 tf[2][6];
     {
-        f32x4 v[2][6][2], gm[6][2], bt[6][2];
+        f32x4 gm[12], bt[12];
+        if (!MLP || blk == 0) {
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + 8 * g;
+            for (int tg = 0; tg < 2; ++tg) {
+                const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + g * 16;
 #pragma unroll
-            for (int st = 0; st < 6; ++st) {
-                v[tg][st][0] = *reinterpret_cast<const f32x4*>(xr + 32 * st);
-                v[tg][st][1] = *reinterpret_cast<const f32x4*>(xr + 32 * st + 4);
+                for (int n = 0; n < 12; ++n) xcar[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + (n & 3) * 4);
             }
         }
 #pragma unroll
-        for (int st = 0; st < 6; ++st)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                gm[st][hh] = *reinterpret_cast<const f32x4*>(gamma + 32 * st + 8 * g + 4 * hh);
-                bt[st][hh] = *reinterpret_cast<const f32x4*>(beta + 32 * st + 8 * g + 4 * hh);
-            }
+        for (int n = 0; n < 12; ++n) {
+            gm[n] = *reinterpret_cast<const f32x4*>(gamma + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
+            bt[n] = *reinterpret_cast<const f32x4*>(beta + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
+        }
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) {
             float sum = 0.f;
 #pragma unroll
             for (int st = 0; st < 6; ++st)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sum += v[tg][st][0][e] + v[tg][st][1][e];
+                for (int e = 0; e < 4; ++e) sum += xcar[tg][2 * st][e] + xcar[tg][2 * st + 1][e];
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
             const float mean = sum * (1.0f / DIM);
             float ss = 0.f;
 #pragma unroll
-            for (int st = 0; st < 6; ++st)
+            for (int n = 0; n < 12; ++n)
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = v[tg][st][hh][e] - mean; ss += d * d; }
+                for (int e = 0; e < 4; ++e) { const float d = xcar[tg][n][e] - mean; ss += d * d; }
             ss += __shfl_xor(ss, 16);
             ss += __shfl_xor(ss, 32);
             const float rstd = rsqrtf(ss * (1.0f / DIM) + 1e-5f);
@@ -201,9 +202,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 uint32_t pk[4];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
+                    const int n = 2 * st + hh;
                     float o4[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (v[tg][st][hh][e] - mean) * rstd * gm[st][hh][e] + bt[st][hh][e];
+                    for (int e = 0; e < 4; ++e) o4[e] = (xcar[tg][n][e] - mean) * rstd * gm[n][e] + bt[n][e];
                     pk[2 * hh] = pack_bf16x2(o4[0], o4[1]);
                     pk[2 * hh + 1] = pack_bf16x2(o4[2], o4[3]);
                 }
@@ -664,6 +666,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                         *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
                 }
             }
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                for (int n = 0; n < 12; ++n) xcar[tg][n] = acc2[tg][n];        // the next block's LayerNorm1 input
             if constexpr (STAMPS) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 B32_STAMP(P_STORE);

@@ -58,7 +58,8 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
         # all six blocks in ONE launch (csrc/fused_attn.hip, or fused_block64.hip with one wave per window)
         table = ops.block_table([(pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
                                   pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
-                                  pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)])
+                                  pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)],
+                                natural_k=ops.block_tokens_per_wave == 64)
         return ops.fused_blocks64(x, table) if ops.block_tokens_per_wave == 64 else ops.fused_blocks32(x, table)
     for i in range(BLOCKS):
         qkv = None

@@ -275,8 +275,8 @@ def fused_attn_block(x, gamma, beta, wh, bh, bias_frag, wproj, bproj):
 block_tokens_per_wave = int(os.environ.get("TUP_BLOCK_TOKENS_PER_WAVE", "32"))
 
 
-def block_table(blocks):
-    """Pointer table for tup_fused_blocks64_fwd: `blocks` = per block the 13 tensors (gamma1, beta1, wh, bh, bias_frag, wproj,
+def block_table(blocks, natural_k=False):
+    """Pointer table for tup_fused_blocks32_fwd / tup_fused_blocks64_fwd (natural_k=True): `blocks` = per block the 13 tensors (gamma1, beta1, wh, bh, bias_frag, wproj,
     bproj, gamma2, beta2, w1, b1, w2, b2), validated here.  Returns (ctypes array [nblk*13] of device pointers, nblk, the tensors
     -- kept alive by the caller holding the tuple)."""
     import ctypes
@@ -284,6 +284,8 @@ def block_table(blocks):
               (F32, (192,)), (F32, (192,)), (F32, (192,)), (BF16, (768, 192)), (F32, (768,)), (BF16, (192, 768)), (F32, (192,))]
     if not 1 <= len(blocks) <= 8:
         raise ValueError("1..8 blocks per launch")
+    if natural_k:       # for tup_fused_blocks64_fwd: qkv head weights with their K columns in channel order
+        blocks = [tuple(b[:2]) + (_wh_natural_k(b[2]),) + tuple(b[3:]) for b in blocks]
     ptrs = []
     for blk in blocks:
         assert len(blk) == 13
@@ -298,6 +300,19 @@ def fused_blocks32(x, table):
     arr, nblk, _keep = table
     _lib.call("tup_fused_blocks32_fwd", _chk(x, F32, (M, 192), "x"), arr, nblk, M // 64, _stream())
     return x
+
+
+_WH_NATURAL = {}
+
+
+def _wh_natural_k(wh):
+    """The one-wave-per-window kernel (fused_block64.hip) reads LayerNorm1 in natural channel order: undo the K-column order
+    packing.pack_qkv_heads gives the default kernels."""
+    from . import packing
+    dev = wh.device
+    if str(dev) not in _WH_NATURAL:
+        _WH_NATURAL[str(dev)] = torch.argsort(packing._fused_k_order(dev))
+    return wh.index_select(2, _WH_NATURAL[str(dev)]).contiguous()
 
 
 def fused_blocks64(x, table):
@@ -315,7 +330,7 @@ def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2
     assert M % 64 == 0
     tpw = block_tokens_per_wave if tokens_per_wave is None else tokens_per_wave
     if tpw == 64:
-        return fused_blocks64(x, block_table([(gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2)]))
+        return fused_blocks64(x, block_table([(gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2)], natural_k=True))
     _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
               _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
               _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"),

@@ -100,18 +100,28 @@ def pack_fc1_fused(weight: torch.Tensor):
     """mlp.0 weight for tup_fused_mlp_fwd: pack_linear plus a column permutation.  K-step st of the kernel's FC1, lane
     group g, element j contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j -- the channels whose residual the same
     lane carries in its FC2 accumulators -- so packed column 32st + 8g + j holds that channel."""
+    return pack_linear(weight).index_select(1, _fused_k_order(weight.device)).contiguous()
+
+
+def _fused_k_order(device):
+    """Column order of the weights that follow a LayerNorm inside the fused block kernels: K-step st, lane group g, element j
+    contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j (the channels whose residual the same lane carries in its accumulators)."""
     def build():
         k = torch.arange(192)
         st, g, j = k // 32, (k % 32) // 8, k % 8
         return 64 * (st // 2) + 16 * g + 8 * (st % 2) + j
-    return pack_linear(weight).index_select(1, _dev_index("fc1_fused", build, weight.device)).contiguous()
+    return _dev_index("fc1_fused", build, device)
 
 
-def pack_qkv_heads(weight: torch.Tensor, bias: torch.Tensor, heads: int = 12):
-    """attn.qkv Linear [3*dim][dim] -> per head the 16 q, 16 k, 16 v weight rows in natural channel order + 16 zero rows:
-    bf16 [heads][64][dim], and the matching biases fp32 [heads][48] (tup_fused_qkv_attn_fwd)."""
+def pack_qkv_heads(weight: torch.Tensor, bias: torch.Tensor, heads: int = 12, natural_k: bool = False):
+    """attn.qkv Linear [3*dim][dim] -> per head the 16 q, 16 k, 16 v weight rows + 16 zero rows: bf16 [heads][64][dim], and the
+    matching biases fp32 [heads][48] (tup_fused_qkv_attn_fwd and the kernels built on it).  The K columns are in the order of
+    pack_fc1_fused (LayerNorm1 reads the residual stream in the layout of the accumulators that produce it); natural_k=True
+    keeps the channel order (dim = 192 only for the permuted form)."""
     dim = weight.shape[1]
     w = weight.detach().reshape(3, heads, 16, dim).permute(1, 0, 2, 3).reshape(heads, 48, dim)
+    if not natural_k and dim == 192:
+        w = w.index_select(2, _fused_k_order(weight.device))
     wh = torch.zeros(heads, 64, dim, dtype=weight.dtype, device=weight.device)
     wh[:, :48] = w
     bh = bias.detach().reshape(3, heads, 16).permute(1, 0, 2).reshape(heads, 48).float().contiguous()

@@ -252,7 +252,7 @@ def main():
 
         def step():
             opt.zero_grad(set_to_none=True)
-            loss = l1_loss(tm(lr, upscale_factor=6), hr)          # nn.L1Loss (train.py:103,132) on the HIP kernels
+            loss = l1_loss(tm(lr, upscale_factor=6), hr, fuse_into_model_backward=True)     # nn.L1Loss (train.py:103,132)
             loss.backward()
             opt.step()
             return loss.detach()

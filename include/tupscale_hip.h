@@ -271,10 +271,12 @@ int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga, float* tm
  * touches) and dense column tables: band_r0 / band_n int [ceil(Ha/16)] = first output row / row count of band b, band_w fp32
  * [nbands][nr_max][16] = weight of output row band_r0[b] + i for source row 16 b + k (zero where none); xoT int / xwT fp32
  * [kmax][Wa] = entry k of source column x's transposed tap list (padding: weight 0); blk_c0 / blk_n int [ceil(Wa/256)] = the
- * stretch (<= 4096 columns) of a tmp row that source columns 256 j .. 256 j + 255 read. */
+ * stretch (<= 4096 columns) of a tmp row that source columns 256 j .. 256 j + 255 read.  l1_scale (device scalar, or NULL): when
+ * given, `gout` is the TARGET of nn.L1Loss (train.py:103,132) applied to the forward output and the upstream gradient
+ * sign(out - target) * l1_scale[0] is formed inside the row pass instead of being read. */
 int tup_rt_bicubic_bwd_banded(const float* gout, const float* out, float* ga, float* tmp, const int* band_r0, const int* band_n,
                               const float* band_w, int nr_max, const int* xoT, const float* xwT, int kmax, const int* blk_c0,
-                              const int* blk_n, int planes, int Ha, int Wa, int Ho, int Wo, void* stream);
+                              const int* blk_n, int planes, int Ha, int Wa, int Ho, int Wo, const float* l1_scale, void* stream);
 
 /* ---- frame pre/post-processing either side of the model ---- */
 

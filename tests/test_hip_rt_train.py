@@ -144,3 +144,34 @@ def test_full_size_train_grads_match_reference_fixture(golden_dir):
         assert e_s <= 0.10, f"{k}: sampled max err {e_s:.4f} of max|g|"
         assert e_n <= 0.05, f"{k}: norm err {e_n:.4f}"
     print("worst sampled", worst_s, "worst norm", worst_n)
+
+
+def test_l1_gradient_fused_into_model_backward():
+    """autograd.l1_loss(..., fuse_into_model_backward=True): the loss gradient is formed inside the bicubic backward's row pass
+    instead of being materialised.  Same loss and (up to the order of a few fp32 sums: none here, the row pass is identical) the
+    same parameter gradients as the two-node path; a model output with a second consumer is refused loudly."""
+    from transformerupscaler_amd.autograd import l1_loss
+    from transformerupscaler_amd.weights import rt_deterministic_state_dict
+    m = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
+    m.load_state_dict(rt_deterministic_state_dict(0))
+    m = m.cuda().eval()                                   # eval: no dropout, the two runs see the same forward
+    g = torch.Generator().manual_seed(31)
+    lr = torch.rand((1, 3, 720, 1280), generator=g).cuda()       # the position embedding fixes the token grid (model.py:140)
+    hr = torch.rand((1, 3, 1440, 2560), generator=g).cuda()
+    grads = []
+    for fuse in (False, True):
+        m.zero_grad(set_to_none=True)
+        loss = l1_loss(m(lr, upscale_factor=2), hr, fuse_into_model_backward=fuse)
+        loss.backward()
+        grads.append((loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert grads[0][0] == grads[1][0]
+    assert set(grads[0][1]) == set(grads[1][1]) and len(grads[0][1]) > 50
+    for k in grads[0][1]:
+        a, b = grads[0][1][k], grads[1][1][k]
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-9 + 1e-6 * a.abs().max().item()), k
+    # a second consumer of the model output: its gradient is not the loss's stand-in
+    m.zero_grad(set_to_none=True)
+    out = m(lr, upscale_factor=2)
+    total = l1_loss(out, hr, fuse_into_model_backward=True) + 1e-3 * out.mean()
+    with pytest.raises(RuntimeError, match="consumer besides the loss"):
+        total.backward()

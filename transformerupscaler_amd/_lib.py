@@ -46,7 +46,7 @@ SIGNATURES = {
     "tup_rt_patch_wgrad": [P, P, P, I, I, I, P],
     "tup_conv3x3_c64_wgrad_s2d": [P, P, P, P, I, I, I, I, I, P],
     "tup_rt_bicubic_bwd": [P] * 10 + [I, I, I, I, I, P],
-    "tup_rt_bicubic_bwd_banded": [P] * 7 + [I, P, P, I, P, P, I, I, I, I, I, P],
+    "tup_rt_bicubic_bwd_banded": [P] * 7 + [I, P, P, I, P, P, I, I, I, I, I, P, P],
     "tup_relpos_bias_expand_h": [P, P, I, P],
     "tup_relpos_bias_expand_n_h": [P, P, I, P],
     "tup_window_attn_bwd_h": [P, P, P, P, P, P, P, I, I, F, U, P],

@@ -286,20 +286,36 @@ class _L1LossFn(torch.autograd.Function):
     """nn.L1Loss() (train.py:103,132) with a HIP forward and backward: two streaming passes instead of aten's six."""
 
     @staticmethod
-    def forward(ctx, out, target):
+    def forward(ctx, out, target, model_node):
         out = out.contiguous().float()
         target = target.contiguous().float()
         ctx.save_for_backward(out, target)
+        ctx.model_node = model_node
         part = ops.l1_loss_partial(out, target)
         return (part.double().sum() / out.numel()).float()
 
     @staticmethod
     def backward(ctx, g):
         out, target = ctx.saved_tensors
-        return ops.l1_loss_bwd(out, target, g.contiguous().float().reshape(1)), None
+        if ctx.model_node is not None:
+            # hand (target, d loss / numel) to the model's backward node, which forms sign(out - target) * scale inside its first
+            # kernel; what is returned here is a stride-0 stand-in of the right shape that node recognises and never reads
+            scale = (g.detach().float().reshape(1) / out.numel()).contiguous()
+            stand_in = scale.expand(out.shape)
+            ctx.model_node._fused_l1 = (target, scale, stand_in)
+            return stand_in, None, None
+        return ops.l1_loss_bwd(out, target, g.contiguous().float().reshape(1)), None, None
 
 
-def l1_loss(out: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+def l1_loss(out: torch.Tensor, target: torch.Tensor, fuse_into_model_backward: bool = False) -> torch.Tensor:
+    """nn.L1Loss()(out, target).  fuse_into_model_backward=True (the training harness, where the model output feeds the loss and
+    nothing else, train.py:124-136): when `out` comes straight from a model whose backward supports it (ResidualTransformer), the
+    loss gradient is not materialised -- the model's first backward kernel computes sign(out - target) / numel itself.  The model's
+    backward raises if it then receives anything but that stand-in (an output with a second consumer)."""
     if out.shape != target.shape:
         raise ValueError(f"l1_loss: output {tuple(out.shape)} and target {tuple(target.shape)} differ (train.py:132 compares equal shapes)")
-    return _L1LossFn.apply(out, target)
+    node = None
+    if fuse_into_model_backward and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() \
+            and getattr(getattr(out.grad_fn, "_forward_cls", None), "accepts_fused_l1", False):
+        node = out.grad_fn
+    return _L1LossFn.apply(out, target, node)

@@ -47,7 +47,7 @@ def forward_train(pk, x, res_out, drop_p: float, seed: int):
     return out, sv
 
 
-def backward_train(pk, sv, gout, reducer=None) -> Dict[str, torch.Tensor]:
+def backward_train(pk, sv, gout, reducer=None, l1_scale=None) -> Dict[str, torch.Tensor]:
     g: Dict[str, torch.Tensor] = {}
 
     def ready(*names):
@@ -58,9 +58,10 @@ def backward_train(pk, sv, gout, reducer=None) -> Dict[str, torch.Tensor]:
     B, _, H, W = x.shape
     hd, wd = H // 2, W // 2
     N = (hd // 8) * (wd // 8)
+    # ---- clamp + bicubic (only the residual branch carries parameters); l1_scale: gout is the target of an L1 loss on the
+    #      output and the loss gradient is formed inside the kernel (autograd.l1_loss(..., fuse_into_model_backward=True)) ----
     gout = gout.contiguous().float()
-    # ---- clamp + bicubic (only the residual branch carries parameters) ----
-    g_res = ops.rt_bicubic_bwd(gout, sv["out"], (hd, wd))
+    g_res = ops.rt_bicubic_bwd(gout, sv["out"], (hd, wd), l1_scale=l1_scale)
     # ---- decoder_conv2 (64->3), decoder_conv1's ReLU, decoder_conv1 ----
     dwp, db = ops.conv_thin_wgrad(sv["dec"], g_res, True)
     g["decoder_conv2.weight"], g["decoder_conv2.bias"] = dwp.permute(0, 2, 1).reshape(3, 64, 3, 3), db
@@ -122,6 +123,8 @@ def backward_train(pk, sv, gout, reducer=None) -> Dict[str, torch.Tensor]:
 
 
 class _ResidualTransformerFn(torch.autograd.Function):
+    accepts_fused_l1 = True          # autograd.l1_loss may hand (target, scale) to this node instead of a gradient tensor
+
     @staticmethod
     def forward(ctx, module, x, res_out, names, *params):
         pk = module.packed(backward=True)
@@ -135,9 +138,18 @@ class _ResidualTransformerFn(torch.autograd.Function):
         reducer = getattr(ctx.module, "_grad_reducer", None)
         if reducer is not None:
             reducer.begin(ctx.names)          # raises if this step's parameters are not in the reducer's layout
+        fused = getattr(ctx, "_fused_l1", None)
+        l1_scale = None
+        if fused is not None:
+            target, l1_scale, stand_in = fused
+            ctx._fused_l1 = None
+            if gout.data_ptr() != stand_in.data_ptr() or any(st != 0 for st in gout.stride()):
+                raise RuntimeError("l1_loss(..., fuse_into_model_backward=True): the model output has a consumer besides the loss "
+                                   "(its gradient is not the loss's stand-in); call l1_loss without the fusion")
+            gout = target
         ops.zero_pool_begin(gout.device)
         try:
-            grads = backward_train(ctx.pk, ctx.sv, gout, reducer)
+            grads = backward_train(ctx.pk, ctx.sv, gout, reducer, l1_scale=l1_scale)
         except BaseException:
             if reducer is not None:
                 reducer._abort()

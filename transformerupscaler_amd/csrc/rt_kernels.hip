@@ -596,12 +596,17 @@ __global__ __launch_bounds__(256) void rt_bicubic_bwd_rows_kernel(
 // Row pass in bands of BIC_YB source rows: the output rows a band touches are one contiguous range [r0, r0 + n), every one of
 // them is read ONCE (gradient + clamp gate) and feeds the band's BIC_YB accumulators through a dense, wave-uniform weight row
 // (scalar loads).  The per-source-row gather above reads every output row four times at x6 (6.4 GB of requests for 1.6 GB).
+// L1 = true: the upstream gradient is nn.L1Loss's, formed on the fly -- gout is the TARGET of the loss and the gradient of output
+// element o is sign(o - target) * l1_scale[0] (l1_scale = grad_of_loss / numel, on the device): the 796 MB gradient tensor of the
+// x6 configuration is never written or read (l1_bwd_kernel: 0.5 ms per step).
 constexpr int BIC_YB = 16;
+template <bool L1>
 __global__ __launch_bounds__(256) void rt_bicubic_bwd_rows_band_kernel(
     const float* __restrict__ gout, const float* __restrict__ out, float* __restrict__ tmp,
     const int* __restrict__ band_r0, const int* __restrict__ band_n, const float* __restrict__ band_w, int nr_max,
-    int Ha, int Ho, int Wo)
+    int Ha, int Ho, int Wo, const float* __restrict__ l1_scale)
 {
+    const float gs = L1 ? l1_scale[0] : 0.f;
     const int ox = blockIdx.x * 256 + threadIdx.x;
     const int band = blockIdx.y, plane = blockIdx.z;
     if (ox >= Wo) return;
@@ -623,7 +628,9 @@ __global__ __launch_bounds__(256) void rt_bicubic_bwd_rows_band_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i + u >= n) break;                           // wave-uniform
-            const float g = (ov[u] > 0.f && ov[u] < 1.f) ? gv[u] : 0.f;
+            float g = gv[u];
+            if constexpr (L1) { const float d = ov[u] - gv[u]; g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f); }
+            g = (ov[u] > 0.f && ov[u] < 1.f) ? g : 0.f;
 #pragma unroll
             for (int k = 0; k < BIC_YB; ++k) acc[k] = fmaf(wrow[(size_t)(i + u) * BIC_YB + k], g, acc[k]);
         }
@@ -823,18 +830,24 @@ extern "C" int tup_rt_bicubic_bwd(const float* gout, const float* out, float* ga
 // [nbands][nr_max][16] = weight of output row r0 + i for source row 16b + k (zero where none; rows i >= n are not read);
 // xoT int / xwT fp32 [kmax][Wa] = entry k of source column x's transposed tap list (padded: weight 0, any in-range index),
 // blk_c0 / blk_n int [ceil(Wa/256)] = first tmp column and count (<= 4096) the lists of source columns 256j .. 256j+255 touch.
-// Same results up to the order of the fp32 sums.
+// Same results up to the order of the fp32 sums.  l1_scale != NULL: `gout` is the TARGET of nn.L1Loss on the forward output and
+// the upstream gradient is sign(out - target) * l1_scale[0] (device scalar = d loss / numel), never materialised.
 extern "C" int tup_rt_bicubic_bwd_banded(const float* gout, const float* out, float* ga, float* tmp, const int* band_r0,
                                          const int* band_n, const float* band_w, int nr_max, const int* xoT, const float* xwT,
                                          int kmax, const int* blk_c0, const int* blk_n, int planes, int Ha, int Wa, int Ho, int Wo,
-                                         void* stream)
+                                         const float* l1_scale, void* stream)
 {
     if (planes <= 0) return 0;
     const int nbands = (Ha + BIC_YB - 1) / BIC_YB;
     if (planes > 65535 || Ha > 65535 || nbands > 65535 || nr_max < 1 || kmax < 1) return (int)hipErrorInvalidValue;
+    if (l1_scale != nullptr && out == nullptr) return (int)hipErrorInvalidValue;      // the L1 form needs the forward output
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    rt_bicubic_bwd_rows_band_kernel<<<dim3((Wo + 255) / 256, nbands, planes), dim3(256), 0, s>>>(
-        gout, out, tmp, band_r0, band_n, band_w, nr_max, Ha, Ho, Wo);
+    if (l1_scale != nullptr)
+        rt_bicubic_bwd_rows_band_kernel<true><<<dim3((Wo + 255) / 256, nbands, planes), dim3(256), 0, s>>>(
+            gout, out, tmp, band_r0, band_n, band_w, nr_max, Ha, Ho, Wo, l1_scale);
+    else
+    rt_bicubic_bwd_rows_band_kernel<false><<<dim3((Wo + 255) / 256, nbands, planes), dim3(256), 0, s>>>(
+        gout, out, tmp, band_r0, band_n, band_w, nr_max, Ha, Ho, Wo, nullptr);
     TUP_CHECK_LAUNCH();
     rt_bicubic_bwd_cols_dense_kernel<<<dim3((Wa + 255) / 256, Ha, planes), dim3(256), 0, s>>>(tmp, ga, xoT, xwT, kmax, blk_c0, blk_n, Ha, Wa, Wo);
     TUP_CHECK_LAUNCH();

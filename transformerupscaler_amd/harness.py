@@ -26,7 +26,7 @@ def train_step(model, optimizer, lr_batch: torch.Tensor, hr_batch: torch.Tensor)
     out = model(lr_batch, res_out=tuple(hr_batch.shape[2:]), require_ratio=False)      # train.py:124
     if tuple(out.shape[2:]) != tuple(hr_batch.shape[2:]):
         out = resize_aa(out, tuple(hr_batch.shape[2:]))                      # train.py:127-130
-    loss = l1_loss(out, hr_batch)                                            # train.py:103,132,136 (HIP forward + backward)
+    loss = l1_loss(out, hr_batch, fuse_into_model_backward=True)             # train.py:103,132,136 (HIP forward + backward; `out` feeds nothing else)
     loss.backward()                                                          # train.py:138 (bf16 needs no GradScaler)
     optimizer.step()                                                         # train.py:139
     return loss.detach()

@@ -777,9 +777,10 @@ def _bicubic_cols_on(device, in_size, out_size):
     return _BICC_CACHE[key]
 
 
-def rt_bicubic_bwd(gout, out, in_hw):
+def rt_bicubic_bwd(gout, out, in_hw, l1_scale=None):
     """Gradient of clamp(bicubic(src -> size) + ...) w.r.t. a planar fp32 source of size in_hw; `out` = the saved
-    forward output (the clamp gate) or None."""
+    forward output (the clamp gate) or None.  l1_scale (fp32 device scalar): `gout` is then the TARGET of an L1 loss on `out`
+    and the upstream gradient sign(out - target) * l1_scale is formed inside the kernel."""
     B, C, Ho, Wo = gout.shape
     Ha, Wa = in_hw
     ga = torch.empty((B, C, Ha, Wa), dtype=F32, device=gout.device)
@@ -790,8 +791,11 @@ def rt_bicubic_bwd(gout, out, in_hw):
         xoT, xwT, kmax, c0, cn = cols
         _lib.call("tup_rt_bicubic_bwd_banded", _chk(gout, F32, None, "gout"), _opt(out, F32, (B, C, Ho, Wo), "out"), ga.data_ptr(),
                   tmp.data_ptr(), r0.data_ptr(), bn.data_ptr(), bw.data_ptr(), nr_max, xoT.data_ptr(), xwT.data_ptr(), kmax,
-                  c0.data_ptr(), cn.data_ptr(), B * C, Ha, Wa, Ho, Wo, _stream())
+                  c0.data_ptr(), cn.data_ptr(), B * C, Ha, Wa, Ho, Wo,
+                  None if l1_scale is None else _chk(l1_scale, F32, None, "l1_scale"), _stream())
         return ga
+    if l1_scale is not None:
+        raise RuntimeError("the fused L1 form of rt_bicubic_bwd needs the banded kernels (ratio too large or TUP_BICUBIC_BWD_GATHER set)")
     xs, xo, xw = _bicubic_t_on(gout.device, Wa, Wo)
     ys, yo, yw = _bicubic_t_on(gout.device, Ha, Ho)
     _lib.call("tup_rt_bicubic_bwd", _chk(gout, F32, None, "gout"), _opt(out, F32, (B, C, Ho, Wo), "out"), ga.data_ptr(), tmp.data_ptr(),

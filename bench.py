@@ -4,7 +4,13 @@ configs[1]); one "step" = one forward pass of the hot path over one batch of syn
 are already resident in HBM.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          # N > 1 without RANK in the environment: starts the N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no RANK in the environment re-launches this script as N ranks under torch.distributed.run (a CHILD
+process, started before anything here touches the GPU), relays the child's single JSON line and exits with its code; under
+torchrun (RANK set) the script is one of the ranks.  At N > 1 the line carries `rccl`: what the live process group and the
+gradient reducer report (ranks, backend, buckets, bytes all-reduced per step).
 
 Inference shards by images with no data-path collective (replicas, weak scaling).  Prints ONE JSON
 line on rank 0 (contract in the task statement).  ``roofline`` describes the kernel with the largest
@@ -132,6 +138,63 @@ def pmc_traffic(kernel_key: str):
         return None, f"unavailable ({type(e).__name__})"
 
 
+def launcher_decision(gpus: int, environ) -> str:
+    """"inline" = run the benchmark in this process (N = 1, or this process is already a rank of a torchrun job);
+    "spawn" = start `gpus` ranks with torch.distributed.run and relay their line.  Pure host logic (tests/test_bench_launcher.py)."""
+    if "RANK" in environ or "LOCAL_RANK" in environ or "TORCHELASTIC_RUN_ID" in environ:
+        return "inline"
+    return "spawn" if int(gpus) > 1 else "inline"
+
+
+def launcher_command(gpus: int, argv, port: int):
+    """The child command line: one process per GPU on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(gpus: int, argv) -> int:
+    """Run the N-rank job as a child and relay its ONE JSON line (everything else the ranks print goes to stderr)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(gpus, argv, _free_port())
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without printing a JSON line\n")
+        return 1
+    return proc.returncode
+
+
+def build_info():
+    """Compiler that built the shipped library + the scratch guard's verdict (csrc/check_resources.py), if the build left it."""
+    try:
+        with open(os.path.join(ROOT, "transformerupscaler_amd", "csrc", "build", "resource_usage.json")) as f:
+            ru = json.load(f)
+        guarded = {k: v for k, v in ru["kernels"].items() if v.get("guarded_no_scratch")}
+        return {"hipcc": ru.get("compiler"), "guarded_kernels": len(guarded),
+                "guarded_scratch_bytes_max": max([v.get("scratch_bytes_per_lane", 0) for v in guarded.values()] + [0]),
+                "whole_block_kernel_scratch_bytes": max([v.get("scratch_bytes_per_lane", 0) for k, v in guarded.items()
+                                                         if "fused_qkv_attn_kernel<true, true, false>" in k] + [0])}
+    except Exception as e:          # noqa: BLE001
+        return {"hipcc": None, "note": f"build/resource_usage.json unavailable ({type(e).__name__})"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +209,9 @@ def main():
                          "ResidualTransformer 6x training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if launcher_decision(args.gpus, os.environ) == "spawn":          # before any GPU call in this process
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,6 +266,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def rccl_info(dp):
+        """What the LIVE process group and this model's gradient reducer report (nothing here is a constant of the script)."""
+        if dist is None or dp is None:
+            return None
+        red = dp.reducer
+        return {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "collective": "all_reduce(sum) per bucket on a side stream, issued from inside the backward",
+                "buckets": len(red.bucket_ranges), "bucket_bytes": [4 * (b - a) for a, b in red.bucket_ranges],
+                "bytes_per_step": 4 * red.total_floats, "buckets_issued_last_step": len(red.launched_order)}
+
     def run_train():
         """BASELINE.json configs[2]: 2x 720p->1080p bf16 training step (forward, antialiased resize to the HR
         size, L1, hand-written backward, RCCL gradient all-reduce overlapped with backward, Adam), 4 images/GPU."""
@@ -228,8 +303,9 @@ def main():
             t = torch.tensor([dtt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtt = float(t.item())
+        rccl = rccl_info(dp)
         del dp
-        return {"metric": "images/sec, FastTransformer 2x 720p->1080p training step", "value": world * args.train_batch * args.steps / dtt,
+        return {"rccl": rccl, "metric": "images/sec, FastTransformer 2x 720p->1080p training step", "value": world * args.train_batch * args.steps / dtt,
                 "unit": "images/sec", "ms_per_step": dtt / args.steps * 1e3, "images_per_gpu_per_step": args.train_batch,
                 "global_batch": world * args.train_batch, "loss": float(loss.item()), "dropout": "p=0.1 (train mode, stateless hash masks)",
                 "parallelism": f"dp{world}" + (" RCCL all-reduce of 17.9 MB fp32 grads in ~6 MB buckets, overlapped with backward" if world > 1 else ""),
@@ -273,8 +349,9 @@ def main():
             t = torch.tensor([dtt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtt = float(t.item())
+        rccl = rccl_info(dp)
         del dp
-        return {"metric": "images/sec, ResidualTransformer 6x 720p->4320x7680 training step", "value": world * args.rt_batch * steps / dtt,
+        return {"rccl": rccl, "metric": "images/sec, ResidualTransformer 6x 720p->4320x7680 training step", "value": world * args.rt_batch * steps / dtt,
                 "unit": "images/sec", "ms_per_step": dtt / steps * 1e3, "steps": steps, "images_per_gpu_per_step": args.rt_batch,
                 "global_batch": world * args.rt_batch, "loss": float(loss.item()), "dropout": "p=0.1 (train mode, stateless hash masks)",
                 "parallelism": f"dp{world}" + (" RCCL all-reduce of 12.8 MB fp32 grads, overlapped with backward" if world > 1 else ""),
@@ -311,6 +388,24 @@ def main():
                 "note": "reference-FLOP rate = the reference's 950.2 GF per image / time; the build executes fewer (the last up-conv + "
                         "PixelShuffle + up1_conv run as one composed 5x5 conv)"}
 
+    def run_overlay():
+        """SURVEY 8(f) rank 4, the live-overlay latency path (reference app_overlay.py:337-420): ONE uint8 720p frame resident on the
+        GPU -> ToTensor -> model(res_out=(2160, 3840)) -> uint8 frame, per frame, synchronised; eager and as one hipGraph replay."""
+        import speed_test
+        go = torch.Generator().manual_seed(4242 + rank)
+        frames = [torch.randint(0, 256, (LR_H, LR_W, 3), dtype=torch.uint8, generator=go).to(dev) for _ in range(4)]
+        res = {"metric": "latency per frame, FastTransformer 720p -> 2160p (3x), batch 1, uint8 frame in -> uint8 frame out on the GPU",
+               "unit": "ms", "frames": 60}
+        for key, graph in (("eager", False), ("graph", True)):
+            out, lat, launch, wall = speed_test.frame_latency(model, frames, (2160, 3840), 60, 5, graph, bgr=True)
+            res[key] = dict(speed_test.latency_summary(lat), unsynced_launch_ms_mean=1e3 * sum(launch) / len(launch),
+                            frames_per_sec=60 / wall)
+        assert tuple(out.shape) == (1, 2160, 3840, 3) and out.dtype == torch.uint8
+        res["note"] = ("p50 / p99 of host wall time from handing the frame over to torch.cuda.synchronize() returning; `graph` = "
+                       "speed_test.py --graph (pre-process + model + post-process captured once, one hipGraphLaunch per frame)")
+        return res
+
+    overlay_result = run_overlay() if args.mode == "both" and world == 1 else None
     x4_result = run_x4() if args.mode in ("x4", "both") else None
     if args.mode == "x4":
         if rank == 0:
@@ -415,12 +510,17 @@ def main():
             "roofline": dominant,
             "roofline_second": second,
         }
+        out["build"] = build_info()
         if train_result is not None:
             out["train"] = train_result
+            if train_result.get("rccl") is not None:
+                out["rccl"] = train_result["rccl"]          # the FastTransformer training step's reducer (configs[2])
         if rt_result is not None:
             out["rt_train"] = rt_result
         if x4_result is not None:
             out["x4"] = x4_result
+        if overlay_result is not None:
+            out["overlay"] = overlay_result
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["fidelity"] = cpu_baseline(model, dev)
             out["psnr_vs_ref_db"] = out["fidelity"]["psnr_vs_ref_db"]

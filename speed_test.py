@@ -42,6 +42,65 @@ def load_frames(args, device):
     return [torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, generator=g).to(device) for _ in range(min(args.frames, 8))], "synthetic"
 
 
+def frame_latency(model, frames, res_out, n_frames, warmup, graph, bgr=False, lr_hw=None):
+    """The live-overlay frame loop (reference app_overlay.py:337-420, speed_test.py:56-75): uint8 HWC frame on the GPU ->
+    [Resize to lr_hw] -> ToTensor -> model(res_out) -> uint8 HWC frame, one frame at a time, each timed to completion
+    (`lat`) and to the return of the asynchronous call (`launch`, what the reference's unsynchronised timer sees).
+    graph=True: the whole frame is captured once into a hipGraph and replayed.  Returns (last output, lat, launch, wall)."""
+    from transformerupscaler_amd import ops
+
+    def one_frame(frame_u8):
+        if lr_hw is not None and tuple(frame_u8.shape[:2]) != tuple(lr_hw):
+            x = ops.resize_frames(frame_u8, lr_hw, to_tensor=True, bgr=bgr)
+        else:
+            x = ops.frames_to_tensor(frame_u8, bgr=bgr)
+        y = model(x, res_out=res_out)
+        return ops.tensor_to_frames(y, bgr=bgr)
+
+    g = static_in = static_out = None
+    with torch.no_grad():
+        for i in range(warmup):
+            out = one_frame(frames[i % len(frames)])
+        torch.cuda.synchronize()
+        if graph:
+            static_in = frames[0].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                one_frame(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = one_frame(static_in)
+            torch.cuda.synchronize()
+
+        def run(frame):
+            if g is None:
+                return one_frame(frame)
+            static_in.copy_(frame)
+            g.replay()
+            return static_out
+
+        lat, launch = [], []
+        t_all = time.perf_counter()
+        for i in range(n_frames):
+            f = frames[i % len(frames)]
+            t0 = time.perf_counter()
+            out = run(f)
+            t1 = time.perf_counter()           # what the reference's speed_test.py measures (no sync)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            launch.append(t1 - t0)
+            lat.append(t2 - t0)
+        wall = time.perf_counter() - t_all
+    return out, lat, launch, wall
+
+
+def latency_summary(lat):
+    lat = sorted(lat)
+    return {"mean": 1e3 * sum(lat) / len(lat), "p50": 1e3 * lat[len(lat) // 2], "p99": 1e3 * lat[min(len(lat) - 1, int(0.99 * len(lat)))]}
+
+
 def main():
     ap = argparse.ArgumentParser(description="Synced speed test for the MI355X upscaler plugins")
     ap.add_argument("--data_dir", type=str, default=None)
@@ -75,57 +134,12 @@ def main():
     model.eval()
     frames, source = load_frames(args, device)
     res_out = tuple(args.res_out)
-
     lr_hw = resolutions[str(args.res_in)]
-
-    def one_frame(frame_u8):
-        if args.source_res and tuple(frame_u8.shape[:2]) != tuple(lr_hw):
-            x = ops.resize_frames(frame_u8, lr_hw, to_tensor=True, bgr=args.bgr)
-        else:
-            x = ops.frames_to_tensor(frame_u8, bgr=args.bgr)
-        y = model(x, res_out=res_out)
-        return ops.tensor_to_frames(y, bgr=args.bgr)
-
-    graph = static_in = static_out = None
-    with torch.no_grad():
-        for i in range(args.warmup):
-            out = one_frame(frames[i % len(frames)])
-        torch.cuda.synchronize()
-        if args.graph:
-            static_in = frames[0].clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                one_frame(static_in)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = one_frame(static_in)
-            torch.cuda.synchronize()
-
-        def run(frame):
-            if graph is None:
-                return one_frame(frame)
-            static_in.copy_(frame)
-            graph.replay()
-            return static_out
-
-        lat, launch = [], []
-        t_all = time.perf_counter()
-        for i in range(args.frames):
-            f = frames[i % len(frames)]
-            t0 = time.perf_counter()
-            out = run(f)
-            t1 = time.perf_counter()           # what the reference's speed_test.py measures (no sync)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            launch.append(t1 - t0)
-            lat.append(t2 - t0)
-        wall = time.perf_counter() - t_all
-    lat.sort()
+    out, lat, launch, wall = frame_latency(model, frames, res_out, args.frames, args.warmup, args.graph, bgr=args.bgr,
+                                           lr_hw=lr_hw if args.source_res else None)
     res = {"model": args.model, "weights": weights, "frames": args.frames, "source": source, "res_in": resolutions[str(args.res_in)],
            "res_out": list(out.shape[1:3]), "graph": bool(args.graph),
-           "latency_ms": {"mean": 1e3 * sum(lat) / len(lat), "p50": 1e3 * lat[len(lat) // 2], "p99": 1e3 * lat[min(len(lat) - 1, int(0.99 * len(lat)))]},
+           "latency_ms": latency_summary(lat),
            "unsynced_launch_ms_mean": 1e3 * sum(launch) / len(launch), "images_per_sec": args.frames / wall,
            "includes": ("uint8 HWC -> Resize (Pillow-exact) -> model -> uint8 HWC on the GPU (no PCIe)" if args.source_res
                         else "uint8 HWC -> model -> uint8 HWC on the GPU (no PCIe)")}

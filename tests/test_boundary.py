@@ -235,3 +235,56 @@ def test_pack_plan_maps_on_cpu(det_sd):
         mp = (plan.map_bf16 if dt == torch.bfloat16 else plan.map_f32)[off:off + ref[k].numel()].long()
         got = torch.where(mp >= 0, flat[mp.clamp(min=0)], torch.zeros(())).to(dt).view(shape)
         assert ref[k].dtype == dt and torch.equal(got, ref[k]), k
+
+
+def test_integration_md_ctypes_snippet_matches_header():
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer would write.  Its `argtypes` / `restype` lines are executed
+    here against a recording stand-in for the library and compared with _lib.SIGNATURES (held equal to include/tupscale_hip.h
+    by test_library_exports_every_declared_symbol), and the example CALL must pass exactly that many arguments (VERDICT r2 #13:
+    the document had drifted to 4 pointers + 8 ints)."""
+    import ctypes
+    from transformerupscaler_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. Binding the C ABI directly"):text.index("## 3. Reference-side mapping")]
+    code = sec[sec.index("```python") + len("```python"):]
+    code = code[:code.index("```")]
+
+    class _Fn:
+        pass
+
+    class _Lib:
+        def __init__(self):
+            self.fns = {}
+
+        def __getattr__(self, name):
+            if name.startswith("tup_"):
+                return self.fns.setdefault(name, _Fn())
+            raise AttributeError(name)
+
+    lib = _Lib()
+    sig_lines = [ln for ln in code.splitlines() if re.match(r"\s*lib\.tup_\w+\.(argtypes|restype)\s*=", ln)]
+    assert sig_lines, "no argtypes / restype lines found in INTEGRATION.md section 2"
+    exec("\n".join(sig_lines), {"ctypes": ctypes, "lib": lib})
+    assert lib.fns, "the snippet binds no entry point"
+    for name, fn in lib.fns.items():
+        assert name in _lib.SIGNATURES, f"INTEGRATION.md binds {name}, which the header does not declare"
+        assert list(fn.argtypes) == list(_lib.SIGNATURES[name]), (name, fn.argtypes, _lib.SIGNATURES[name])
+        assert fn.restype is ctypes.c_int
+        # the example call passes one value per declared argument
+        m = re.search(r"lib\." + name + r"\((.*?)\)\n\s*if err", code, re.S)
+        assert m, f"no example call of {name} found"
+        call = re.sub(r"#[^\n]*", "", m.group(1))
+        depth, nargs, cur = 0, 0, ""
+        for ch in call:
+            if ch in "([":
+                depth += 1
+            elif ch in ")]":
+                depth -= 1
+            if ch == "," and depth == 0:
+                nargs += bool(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        nargs += bool(cur.strip())
+        assert nargs == len(_lib.SIGNATURES[name]), (name, nargs, len(_lib.SIGNATURES[name]))

@@ -61,5 +61,10 @@ def test_reducer_static_layout_is_backward_order():
     assert order.index("window_blocks.5.mlp.2.weight") < order.index("window_blocks.0.mlp.2.weight") < order.index("patch_embed.weight")
     assert len(red.bucket_ranges) == 3 and all(b > a for a, b in red.bucket_ranges)
     mixed = GradReducer(None, "cpu", scales=(2, 3, 4, 6))
-    assert mixed.mixed and mixed.total_floats > mixed.param_floats          # presence counts ride behind the parameters
+    # which parameters got a gradient on some rank is exchanged on the host (bitmask words), not through the flat buffer
+    assert mixed.mixed and mixed.total_floats == mixed.param_floats and mixed._mask_words == (len(mixed.names) + 61) // 62
     assert mixed.bucket_ranges[-1][1] == mixed.total_floats
+    from transformerupscaler_amd.weights import active_param_names
+    mixed.begin(active_param_names(3))
+    mixed.on_ready(active_param_names(3), {n: torch.zeros(mixed.shapes[n]) for n in active_param_names(3)})
+    assert set(mixed.finish()) == set(active_param_names(3))                 # world 1: exactly what this rank produced

@@ -192,7 +192,9 @@ def test_rt_x6_train_grads_match_reference(golden_dir):
 
 # ---------------------------------------------------------------- gradients with the gates factored out -------------------
 @pytest.mark.parametrize("scale,shape,kw", [(2, (2, 3, 36, 44), dict(res_out=(54, 66))), (4, (1, 3, 20, 28), dict(upscale_factor=4)),
-                                            (3, (2, 3, 24, 40), dict(res_out=(70, 100))), (6, (1, 3, 16, 24), dict(upscale_factor=6))])
+                                            (3, (2, 3, 24, 40), dict(res_out=(70, 100))), (6, (1, 3, 16, 24), dict(upscale_factor=6)),
+                                            # the benchmarked size (BASELINE configs[2], one sample): 14,400 tokens, 240 windows
+                                            (2, (1, 3, 720, 1280), dict(res_out=(1080, 1920)))])
 def test_grads_mask_matched_vs_oracle(det_sd, scale, shape, kw):
     """Backward kernels alone: the oracle's autograd is evaluated at the ReLU / clamp gates the HIP forward actually took
     (oracle.forward(masks=...)), so a gate flipped by bf16 rounding -- which dominates the plain comparison -- no longer

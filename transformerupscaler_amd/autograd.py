@@ -311,11 +311,14 @@ def l1_loss(out: torch.Tensor, target: torch.Tensor, fuse_into_model_backward: b
     """nn.L1Loss()(out, target).  fuse_into_model_backward=True (the training harness, where the model output feeds the loss and
     nothing else, train.py:124-136): when `out` comes straight from a model whose backward supports it (ResidualTransformer), the
     loss gradient is not materialised -- the model's first backward kernel computes sign(out - target) / numel itself.  The model's
-    backward raises if it then receives anything but that stand-in (an output with a second consumer)."""
+    backward raises if it then receives anything but that stand-in (an output with a second consumer).  Under the fusion the
+    gradient that flows into `out` is that stand-in, not sign(out - target) / numel: ``out.grad`` / tensor hooks on `out` would
+    see it, so an `out` that retains its gradient or carries hooks is given the materialised gradient instead (no fusion)."""
     if out.shape != target.shape:
         raise ValueError(f"l1_loss: output {tuple(out.shape)} and target {tuple(target.shape)} differ (train.py:132 compares equal shapes)")
     node = None
     if fuse_into_model_backward and out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() \
+            and not out.retains_grad and not getattr(out, "_backward_hooks", None) \
             and getattr(getattr(out.grad_fn, "_forward_cls", None), "accepts_fused_l1", False):
         node = out.grad_fn
     return _L1LossFn.apply(out, target, node)

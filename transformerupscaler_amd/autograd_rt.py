@@ -135,9 +135,7 @@ class _ResidualTransformerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        reducer = getattr(ctx.module, "_grad_reducer", None)
-        if reducer is not None:
-            reducer.begin(ctx.names)          # raises if this step's parameters are not in the reducer's layout
+        # the fused-L1 hand-off is validated BEFORE the reducer opens its episode: a refusal here must not leave it open
         fused = getattr(ctx, "_fused_l1", None)
         l1_scale = None
         if fused is not None:
@@ -147,6 +145,9 @@ class _ResidualTransformerFn(torch.autograd.Function):
                 raise RuntimeError("l1_loss(..., fuse_into_model_backward=True): the model output has a consumer besides the loss "
                                    "(its gradient is not the loss's stand-in); call l1_loss without the fusion")
             gout = target
+        reducer = getattr(ctx.module, "_grad_reducer", None)
+        if reducer is not None:
+            reducer.begin(ctx.names)          # raises if this step's parameters are not in the reducer's layout
         ops.zero_pool_begin(gout.device)
         try:
             grads = backward_train(ctx.pk, ctx.sv, gout, reducer, l1_scale=l1_scale)

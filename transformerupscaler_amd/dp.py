@@ -16,8 +16,10 @@ Two layouts:
  * ``scales=(2, 3, 4, 6)`` -- ranks / steps may train different scales (the reference dataset mixes
    scales inside one step, data_handling/data_class.py:34-45, train.py:119-133; SURVEY §8(e) "wrinkle").
    The buffer spans the union; a rank contributes zeros for what it did not produce ("missing grads are
-   zeros for the reduce only") and a per-parameter presence count rides in the last bucket, so a parameter
-   gets a gradient iff at least one rank produced one (otherwise ``None`` -> Adam skips it on all ranks).
+   zeros for the reduce only") and the ranks OR their active-parameter bitmasks on the HOST (a small CPU
+   collective over a gloo side group, started in begin() and collected in finish(): no device readback inside
+   the backward), so a parameter gets a gradient iff at least one rank produced one (otherwise ``None`` ->
+   Adam skips it on all ranks).
 
 One backward node = one begin() / on_ready()... / finish() episode; with train.py's per-sample loop
 (several forwards, one ``loss.backward()``) every sample's node runs its own episode, so all ranks must
@@ -95,9 +97,18 @@ class GradReducer:
             cur += (self.numel[n] + 63) // 64 * 64
         self.param_floats = cur
         self.index = {n: i for i, n in enumerate(layout)}
-        self.presence_off = cur                              # mixed layout: one float per parameter, reduced with the last bucket
-        total = cur + ((len(layout) + 63) // 64 * 64 if self.mixed else 0)
-        self.total_floats = total
+        self.total_floats = total = cur
+        # mixed layout: which parameters got a gradient on SOME rank is exchanged on the host (62 names per int64 word, OR-reduced)
+        self._host_group = None
+        if self.mixed and dist.is_initialized() and self.world > 1:
+            if dist.get_backend(process_group) == "gloo":
+                self._host_group = process_group
+            else:                                            # collective call: every rank builds its reducer at the same point
+                ranks = dist.get_process_group_ranks(process_group if process_group is not None else dist.group.WORLD)
+                self._host_group = dist.new_group(ranks=ranks, backend="gloo")
+        self._mask_words = (len(layout) + 61) // 62
+        self._mask_work = None
+        self._mask = None
         self.flat = None          # allocated per backward episode: finish() hands out views of it, which stay valid (and may be
                                   # accumulated into by train.py's per-sample loop) while the next episode fills a fresh buffer
         # buckets of >= bucket_mb in layout order
@@ -115,8 +126,6 @@ class GradReducer:
             self.bucket_ranges.append((a, cur))
         for n in layout:                                     # a trailing short bucket was merged into a new last one above
             self.bucket_of[n] = min(self.bucket_of[n], len(self.bucket_ranges) - 1)
-        if total > cur:                                      # presence counts ride in the last bucket
-            self.bucket_ranges[-1] = (self.bucket_ranges[-1][0], total)
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._works: list = []
         self._in_step = False
@@ -124,7 +133,7 @@ class GradReducer:
         self._arrived: set = set()
         self._pending: List[int] = []
         self._next_bucket = 0
-        self._presence_cache: Dict[frozenset, torch.Tensor] = {}
+        self._mask_cache: Dict[frozenset, torch.Tensor] = {}
         self.launched_order: List[int] = []                  # bucket indices in issue order of the last episode (tests)
 
     # ---- episode start: called by the autograd node before its first gradient ----
@@ -154,12 +163,15 @@ class GradReducer:
         if self.comm_stream is not None and dist.is_initialized():
             self.flat.record_stream(self.comm_stream)        # the all-reduces run on the side stream
         if self.mixed:
-            pres = self._presence_cache.get(act)
-            if pres is None:
-                pres = torch.zeros(self.total_floats - self.presence_off, dtype=torch.float32)
-                pres[[self.index[n] for n in act]] = 1.0
-                pres = self._presence_cache[act] = pres.to(self.device)
-            self.flat[self.presence_off:].copy_(pres)
+            mask = self._mask_cache.get(act)
+            if mask is None:
+                words = [0] * self._mask_words
+                for n in act:
+                    words[self.index[n] // 62] |= 1 << (self.index[n] % 62)
+                mask = self._mask_cache[act] = torch.tensor(words, dtype=torch.int64)
+            self._mask = mask.clone()
+            if self._host_group is not None or (dist.is_initialized() and self.world > 1):
+                self._mask_work = dist.all_reduce(self._mask, op=dist.ReduceOp.BOR, group=self._host_group, async_op=True)
         self._advance()
 
     # ---- called from the backward as soon as a group of gradients is final ----
@@ -227,8 +239,11 @@ class GradReducer:
         if self.world > 1:
             self.flat.mul_(1.0 / self.world)
         if self.mixed:
-            pres = self.flat[self.presence_off:self.presence_off + len(self.names)].cpu()
-            have = [n for n in self.names if pres[self.index[n]].item() > 0.0]
+            if self._mask_work is not None:
+                self._mask_work.wait()                       # host collective, started in begin(): no device sync here
+                self._mask_work = None
+            words = self._mask.tolist()
+            have = [n for n in self.names if (words[self.index[n] // 62] >> (self.index[n] % 62)) & 1]
         else:
             have = [n for n in self.names if n in self._active]
         out = {n: self.flat[self.offset[n]:self.offset[n] + self.numel[n]].view(self.shapes[n]) for n in have}
@@ -239,6 +254,9 @@ class GradReducer:
         for w in self._works:
             w.wait()
         self._works = []
+        if self._mask_work is not None:
+            self._mask_work.wait()
+            self._mask_work = None
         self._in_step, self._active = False, None
 
 

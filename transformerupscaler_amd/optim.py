@@ -31,6 +31,7 @@ class Adam(torch.optim.Adam):
                 loss = closure()
         recs: List[bytes] = []
         sizes: List[int] = []
+        updated: list = []                                     # parameters the launch writes (their version is bumped below)
         keep: list = []                                        # tensors the asynchronous launch reads: alive until the next step
         device = None
         fallback_groups = []
@@ -60,6 +61,7 @@ class Adam(torch.optim.Adam):
                 recs.append(struct.pack("<QQQQqffffff", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                         p.numel(), group["lr"] / bc1, 1.0 / math.sqrt(bc2), beta2, 1.0 - beta1, 1.0 - beta2, group["eps"]))
                 sizes.append(p.numel())
+                updated.append(p)
                 if g is not p.grad:
                     keep.append(g)
         if recs:
@@ -75,16 +77,28 @@ class Adam(torch.optim.Adam):
             # source would make the copy synchronous and stall the host behind the whole backward)
             raw = b"".join(recs)
             stage = self.__dict__.setdefault("_stage", [None, None, 0])
+            events = self.__dict__.setdefault("_stage_events", [None, None])
             slot = stage[2] = stage[2] ^ 1
+            # the host may run several steps ahead of the GPU (no per-step sync in a training loop): a slot is rewritten only
+            # after the asynchronous upload that last read it has executed
+            if events[slot] is not None:
+                events[slot].synchronize()
             if stage[slot] is None or stage[slot].numel() * 8 < len(raw):
                 stage[slot] = torch.empty(len(raw) // 8, dtype=torch.int64).pin_memory()
             host = stage[slot][:len(raw) // 8]
             host.copy_(torch.frombuffer(bytearray(raw), dtype=torch.int64))
-            segs = host.to(device, non_blocking=True)
             from .ops import _stream
             with torch.cuda.device(device):
+                segs = host.to(device, non_blocking=True)
+                if events[slot] is None:
+                    events[slot] = torch.cuda.Event()
+                events[slot].record()
                 _lib.call("tup_adam_step", segs.data_ptr(), chunks.data_ptr(), chunks.shape[0], _stream())
             keep.append(segs)
+            # the launch writes the parameters through raw pointers: tell autograd (saved-tensor checks) and every cache keyed on
+            # (data_ptr, _version) -- the models' packed-weight caches -- that they changed, as an in-place torch update would
+            for p in updated:
+                torch.autograd.graph.increment_version(p)
         self.__dict__["_keep"] = keep
         if fallback_groups:
             saved = self.param_groups

@@ -11,6 +11,7 @@ import test_hip_kernels as T
 nwin, rounds = 1920, 15
 libs = dict(a.split("=") for a in sys.argv[1:])
 raw, args = T._block_operands("cuda", nwin)
+args_bf16 = args
 x0 = raw["x"].to("cuda")
 arr, nblk, keep = ops.block_table([tuple(args)] * 6)
 P, I = ctypes.c_void_p, ctypes.c_int
@@ -18,9 +19,16 @@ runs = {}
 wh_perm = args[2]                                   # as packing.pack_qkv_heads packs it now (K columns in accumulator order)
 wh_nat = ops._wh_natural_k(wh_perm)                 # libraries built before that change: name=path@natural
 keep = [keep]
+from transformerupscaler_amd import packing
+# libraries built with -DTUP_FA_GELU16=1 (name=path@gelu16): mlp.0 scaled by 1/4 (exact), mlp.2 as 4 W2 in fp16
+args16 = list(args)
+args16[9] = packing.pack_fc1_fused(raw["w1"] * 0.25).to("cuda")
+args16[10] = (raw["b1"] * 0.25).to("cuda")
+args16[11] = packing.perm_rows64(raw["w2"] * 4.0).contiguous().to(torch.float16).to("cuda")
 for name, path in libs.items():
     path, _, flag = path.partition("@")
     natural = flag == "natural"
+    args = args16 if flag == "gelu16" else args_bf16
     L = ctypes.CDLL(os.path.join(root, path))
     L.tup_fused_block_fwd.argtypes = [P] * 14 + [I, P]
     ptrs = [a.data_ptr() for a in args]

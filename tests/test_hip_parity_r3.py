@@ -104,8 +104,12 @@ def test_fused_adam_host_runs_ahead_without_corrupting_steps(det_sd):
     for tag in ("async", "sync"):
         m = _ft(det_sd)
         opt = Adam(m.parameters(), lr=1e-3)
+        harness.train_step(m, opt, lr_b, hr_b)                  # builds the pack plan, sizes the staging slots
+        torch.cuda.synchronize()
+        if tag == "async":
+            torch.cuda._sleep(int(1.5e9))                       # the GPU idles ~0.7 s while the host queues the steps below
         losses = []
-        for _ in range(12):
+        for _ in range(8):
             losses.append(harness.train_step(m, opt, lr_b, hr_b))
             if tag == "sync":
                 torch.cuda.synchronize()
@@ -113,13 +117,16 @@ def test_fused_adam_host_runs_ahead_without_corrupting_steps(det_sd):
         res[tag] = ([float(v) for v in losses], [p.detach().clone() for p in m.parameters()])
     la, pa = res["async"]
     ls, ps = res["sync"]
-    for a, b in zip(la, ls):
-        assert abs(a - b) <= 2e-4 * abs(b) + 2e-5, (la, ls)
+    # the same trajectory: the first steps to rounding, the later ones to the divergence that the weight-gradient kernels' fp32
+    # atomics (order-dependent last bits) seed and Adam's +-lr steps amplify -- a step run with another step's lr / bc1 or
+    # gradient pointers would be off by percent
+    for i, (a, b) in enumerate(zip(la, ls)):
+        assert abs(a - b) <= (1e-5 if i < 3 else 2e-3) * abs(b), (i, la, ls)
     tot = bad = 0
     for a, b in zip(pa, ps):
         d = (a - b).abs()
-        tot += d.numel(); bad += int((d > 0.5e-3).sum())
-    assert bad <= 0.01 * tot, (bad, tot)
+        tot += d.numel(); bad += int((d > 1e-3).sum())          # one full +-lr step apart
+    assert bad <= 0.02 * tot, (bad, tot)
 
 
 # ---------------------------------------------------------------- training at the benchmarked batch -----------------------

@@ -70,6 +70,13 @@ int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, const int* y
                       int KY, const int* xmin, const int* xsize, const float* xw, int KX, int planes,
                       int Hi, int Wi, int Ho, int Wo, int clamp01, void* stream);
 
+/* The same output tail for a last stage of r = 2 (scales 2 and 4) WITHOUT the Resize, as a register-streaming stencil (no LDS):
+ * final_upscale's last Conv2d(3,12,3)+PixelShuffle(2) utils.py:62-63,74-75, final_upscale_conv + "+ upscaled_input"
+ * model.py:316-320 [+ clamp model.py:327].  x fp32 [B][3][H][W]; wfu_t fp32 [27][12], wfc_t fp32 [27][4] tap-major
+ * (k = cin*9 + ky*3 + kx; packing.pack_planar_t); bfu [12], bfc [3]; ui / out fp32 [B][3][2H][2W]. */
+int tup_tail_stream_r2_fwd(const float* x, const float* wfu_t, const float* bfu, const float* wfc_t, const float* bfc,
+                           const float* ui, float* out, int B, int H, int W, int clamp01, void* stream);
+
 /* Inference fusion of the output tail (model.py:316-327): last final_upscale stage (Conv2d(3,3rr,3)+PixelShuffle),
  * final_upscale_conv, "+ upscaled_input", Resize (tap tables; identity tables when sizes match) and clamp.
  * x fp32 [B][3][H][W]; ui fp32 [B][3][H*r][W*r]; out fp32 [B][3][Ho][Wo]; EH/EW = largest HR window a 16x64

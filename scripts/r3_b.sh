@@ -1,5 +1,5 @@
 #!/bin/bash
-set -e
+set +e
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3b

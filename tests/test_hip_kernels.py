@@ -467,6 +467,33 @@ def test_tail_fused_vs_unfused(dev, B, H, W, r, out_hw):
     assert 0.05 < ref.mean().item() < 0.95          # the clamp is not saturating the comparison away
 
 
+@pytest.mark.parametrize("B,H,W,clamp", [(2, 40, 72, True), (1, 37, 53, False), (1, 1, 1, True), (1, 2, 3, False), (1, 45, 60, True),
+                                         (1, 46, 61, True), (2, 91, 121, False), (1, 135, 58, True), (1, 5, 200, False)])
+def test_tail_stream_r2_vs_torch_and_unfused(dev, B, H, W, clamp):
+    """tup_tail_stream_r2_fwd (register-streaming output tail for a last stage of r = 2: Conv2d(3,12,3) + PixelShuffle(2),
+    Conv2d(3,3,3), "+ upscaled_input" [+ clamp]; model.py:316-320,327, utils.py:62-63) against torch fp32 on the CPU and against
+    the one-kernel-per-op HIP path.  Sizes cover one wave strip (60 LR columns) and one band (45 LR rows) exactly, one past
+    them, several strips / bands with ragged ends, and the 1 x 1 image (every tap in the zero padding)."""
+    from transformerupscaler_amd import ops, packing
+    x = rnd((B, 3, H, W), 190, 0.4, 0.3)
+    w_fu, b_fu = rnd((12, 3, 3, 3), 191, 0.2), rnd((12,), 192, 0.1)
+    w_fc, b_fc = rnd((3, 3, 3, 3), 193, 0.2), rnd((3,), 194, 0.1)
+    ui = rnd((B, 3, 2 * H, 2 * W), 195, 0.3, 0.4)
+    ref = F.conv2d(F.pixel_shuffle(F.conv2d(x, w_fu, b_fu, padding=1), 2), w_fc, b_fc, padding=1) + ui
+    if clamp:
+        ref = ref.clamp(0, 1)
+    got = ops.tail_stream_r2(x.to(dev), packing.pack_planar_t(w_fu).to(dev), b_fu.to(dev), packing.pack_planar_t(w_fc).to(dev),
+                             b_fc.to(dev), ui.to(dev), clamp=clamp)
+    assert got.shape == ref.shape
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 2e-5, err
+    t1 = ops.conv_planar(x.to(dev), packing.pack_planar(w_fu).to(dev), b_fu.to(dev), 2)
+    unf = ops.conv_planar(t1, packing.pack_planar(w_fc).to(dev), b_fc.to(dev), 1, add=ui.to(dev), clamp=clamp)
+    assert (got - unf).abs().max().item() <= 2e-5
+    if H * W > 100:
+        assert 0.05 < ref.mean().item() < 0.95
+
+
 def test_ln_gemm_fused(dev):
     from transformerupscaler_amd import ops, packing
     M, N = 448, 576

@@ -50,6 +50,7 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
 blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
+stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
 
 
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
@@ -150,6 +151,13 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
         for si, (_, r) in enumerate(fu[:-1]):
             t = ops.conv_planar(t, pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r)
         li = len(fu) - 1
+        if stream_tail and fu[li][1] == 2 and "tail.wfu_t" in pk:
+            with _stage("tail"):
+                out = ops.tail_stream_r2(t, pk["tail.wfu_t"], pk[f"fu.{li}.b"], pk["tail.wfc_t"], pk["fuc.b"], upscaled_input,
+                                         clamp=not needs_resize)
+                if needs_resize:
+                    out = ops.resize_aa(out, tuple(res_out), clamp=True)
+            return out
         with _stage("tail"):
             out = ops.tail_fused(t, pk[f"fu.{li}.w"], pk[f"fu.{li}.b"], pk["fuc.w"], pk["fuc.b"], upscaled_input, fu[li][1],
                                  tuple(res_out) if needs_resize else (hs, ws), clamp=True)

@@ -179,6 +179,16 @@ def tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True):
     return out
 
 
+def tail_stream_r2(x, wfu_t, bfu, wfc_t, bfc, ui, clamp=True):
+    """Last final_upscale stage (r = 2) + final_upscale_conv + "+ upscaled_input" [+ clamp] at the HR size, streaming kernel."""
+    B, C, H, W = x.shape
+    out = torch.empty((B, 3, 2 * H, 2 * W), dtype=F32, device=x.device)
+    _lib.call("tup_tail_stream_r2_fwd", _chk(x, F32, (B, 3, H, W), "x"), _chk(wfu_t, F32, (27, 12), "wfu_t"), _chk(bfu, F32, (12,), "bfu"),
+              _chk(wfc_t, F32, (27, 4), "wfc_t"), _chk(bfc, F32, (3,), "bfc"), _chk(ui, F32, (B, 3, 2 * H, 2 * W), "ui"),
+              out.data_ptr(), B, H, W, int(clamp), _stream())
+    return out
+
+
 def clamp01(x):
     out = torch.empty_like(x)
     _lib.call("tup_clamp01_fwd", _chk(x, F32, None, "x"), out.data_ptr(), x.numel(), _stream())

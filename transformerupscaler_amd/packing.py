@@ -77,6 +77,16 @@ def pack_planar(weight: torch.Tensor):
     return w.contiguous()
 
 
+def pack_planar_t(weight: torch.Tensor):
+    """Conv2d(3, cout, 3) -> fp32 [27][cout padded to a multiple of 4], k = cin*9 + ky*3 + kx: the tap-major order in which the
+    streaming output tail (csrc/tail_stream.hip) reads its wave-uniform weights (one scalar load per tap covers all outputs)."""
+    cout = weight.shape[0]
+    assert weight.shape[1:] == (3, 3, 3)
+    w = torch.zeros(27, (cout + 3) // 4 * 4, dtype=torch.float32, device=weight.device)
+    w[:, :cout] = weight.reshape(cout, 27).float().t()
+    return w.contiguous()
+
+
 def pack_linear(weight: torch.Tensor):
     """nn.Linear weight [N][K] -> bf16 with rows permuted per 64-group."""
     return perm_rows64(weight).contiguous().to(torch.bfloat16)
@@ -244,6 +254,10 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         pk["bra.w"], pk["bra.b"], pk["bra.wv"], pk["bra.bv"] = pack_branch_a(
             sd[k + ".weight"].detach(), sd[k + ".bias"].detach(), sd["up1_conv.conv.weight"].detach(), r)
     pk["fuc.w"] = pack_planar(sd["final_upscale_conv.weight"].detach()); pk["fuc.b"] = f32(sd["final_upscale_conv.bias"])
+    if not backward and upsampler_layout(scale)[-1][1] == 2:      # inference, last stage x2: the streaming output tail's tap-major weights
+        li = len(upsampler_layout(scale)) - 1
+        pk["tail.wfu_t"] = pack_planar_t(sd[f"final_upscale.upsamplers.{scale}.{upsampler_layout(scale)[-1][0]}.weight"].detach())
+        pk["tail.wfc_t"] = pack_planar_t(sd["final_upscale_conv.weight"].detach())
     pk["pe.w"] = pack_patch_embed(sd["patch_embed.weight"].detach()); pk["pe.b"] = f32(sd["patch_embed.bias"])
     for i in range(BLOCKS):
         p = f"window_blocks.{i}"

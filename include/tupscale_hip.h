@@ -77,6 +77,16 @@ int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, const int* y
 int tup_tail_stream_r2_fwd(const float* x, const float* wfu_t, const float* bfu, const float* wfc_t, const float* bfc,
                            const float* ui, float* out, int B, int H, int W, int clamp01, void* stream);
 
+/* ... followed by the antialiased Resize to Ho x Wo (model.py:323-325; tap tables as tup_resize_aa_fwd, at most 4 taps per output)
+ * and the clamp, in the same kernel: out fp32 [B][3][Ho][Wo].  sc = LR columns a wave strip advances by
+ * (<= 60 - ceil((max taps - 1) / 2)), band_h = LR rows per band (multiple of 3), ext = LR rows a band runs past its end
+ * (ceil((max taps - 1) / 2)); oxb int [ceil(W / sc) + 1] / oyb int [ceil(H / band_h) + 1]: first output column / row whose
+ * first tap lies in strip s's HR columns [2 s sc, ...) / band k's HR rows [2 k band_h, ...). */
+int tup_tail_stream_r2_resize_fwd(const float* x, const float* wfu_t, const float* bfu, const float* wfc_t, const float* bfc,
+                                  const float* ui, float* out, const int* ymin, const int* ysize, const float* yw, int KY,
+                                  const int* xmin, const int* xsize, const float* xw, int KX, const int* oxb, const int* oyb,
+                                  int B, int H, int W, int Ho, int Wo, int sc, int band_h, int ext, int clamp01, void* stream);
+
 /* Inference fusion of the output tail (model.py:316-327): last final_upscale stage (Conv2d(3,3rr,3)+PixelShuffle),
  * final_upscale_conv, "+ upscaled_input", Resize (tap tables; identity tables when sizes match) and clamp.
  * x fp32 [B][3][H][W]; ui fp32 [B][3][H*r][W*r]; out fp32 [B][3][Ho][Wo]; EH/EW = largest HR window a 16x64

@@ -494,6 +494,34 @@ def test_tail_stream_r2_vs_torch_and_unfused(dev, B, H, W, clamp):
         assert 0.05 < ref.mean().item() < 0.95
 
 
+@pytest.mark.parametrize("B,H,W,out_hw", [(2, 40, 72, (60, 108)), (1, 37, 53, (55, 80)), (1, 90, 150, (135, 225)), (1, 45, 60, (68, 90)),
+                                          (2, 96, 130, (128, 174)), (1, 30, 200, (45, 300)), (1, 61, 59, (100, 100)),
+                                          (1, 24, 40, (19, 32))])
+def test_tail_stream_r2_fused_resize(dev, B, H, W, out_hw):
+    """tup_tail_stream_r2_resize_fwd: the streaming tail with the antialiased Resize (model.py:323-325) and the clamp inside, against
+    torch fp32 (F.interpolate antialias=True is what torchvision's tensor Resize calls) and against the streaming kernel followed
+    by the separable Resize kernel.  Ratios 4/3 (the benchmark's), 1.36, 1.5 and a non-uniform one; several strips and bands;
+    a down-scale by 2.5 (6 taps) must be refused by the planner (None) so that the caller falls back."""
+    from transformerupscaler_amd import ops, packing
+    x = rnd((B, 3, H, W), 290, 0.4, 0.3)
+    w_fu, b_fu = rnd((12, 3, 3, 3), 291, 0.2), rnd((12,), 292, 0.1)
+    w_fc, b_fc = rnd((3, 3, 3, 3), 293, 0.2), rnd((3,), 294, 0.1)
+    ui = rnd((B, 3, 2 * H, 2 * W), 295, 0.3, 0.4)
+    args = (x.to(dev), packing.pack_planar_t(w_fu).to(dev), b_fu.to(dev), packing.pack_planar_t(w_fc).to(dev), b_fc.to(dev), ui.to(dev))
+    got = ops.tail_stream_r2(*args, clamp=True, out_hw=out_hw)
+    if out_hw == (19, 32):                 # 48 -> 19 rows: scale 2.5, six taps
+        assert got is None
+        return
+    assert got is not None and tuple(got.shape) == (B, 3) + tuple(out_hw)
+    s = F.conv2d(F.pixel_shuffle(F.conv2d(x, w_fu, b_fu, padding=1), 2), w_fc, b_fc, padding=1) + ui
+    ref = F.interpolate(s, size=out_hw, mode="bilinear", align_corners=False, antialias=True).clamp(0, 1)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 2e-5, err
+    two = ops.resize_aa(ops.tail_stream_r2(*args, clamp=False), out_hw, clamp=True)
+    assert (got - two).abs().max().item() <= 2e-5
+    assert 0.05 < ref.mean().item() < 0.95
+
+
 def test_ln_gemm_fused(dev):
     from transformerupscaler_amd import ops, packing
     M, N = 448, 576

@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 P = c_void_p
 I = c_int
@@ -28,6 +28,7 @@ SIGNATURES = {
     "tup_resize_aa_fwd": [P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P],
     "tup_tail_fused_fwd": [P, P, P, P, P, P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "tup_tail_stream_r2_fwd": [P, P, P, P, P, P, P, I, I, I, I, P],
+    "tup_tail_stream_r2_resize_fwd": [P] * 7 + [P, P, P, I, P, P, P, I, P, P] + [I] * 9 + [P],
     "tup_clamp01_fwd": [P, P, c_longlong, P],
     "tup_layernorm_fwd": [P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand": [P, P, P],

@@ -2,7 +2,10 @@
 //     t1  = PixelShuffle(2)(Conv2d(3, 12, 3)(x))            final_upscale        models/FastTransformer/utils.py:62-63,74-75
 //     sum = Conv2d(3, 3, 3)(t1) + upscaled_input            final_upscale_conv   models/FastTransformer/model.py:316-320
 //     out = clamp(sum, 0, 1) (optional)                                          model.py:327
-// (the antialiased Resize of model.py:323-325, when one is needed, follows as its own separable kernel).
+// RESIZE = true appends the antialiased Resize of model.py:323-325 (tap tables of at most 4 taps per axis, i.e. down-scaling by
+// up to 1.5) and the clamp: the pre-resize sums never leave the wave.  Vertically the last 6 HR rows of a lane's two columns sit in
+// a register ring and an output row is emitted as soon as its last input row exists; horizontally the vertically filtered row goes
+// through a 1.5 KB wave-private LDS line from which every lane gathers the taps of its (up to two) output columns.
 //
 // Why not tiles: the tiled kernel (tail_fused.hip) walks the stencil chain through three LDS tiles with a barrier between stages; a
 // tile spends 40 % of its life waiting for its window loads and the rest in short latency-bound phases (VALU floor 3.3 k of its
@@ -27,6 +30,12 @@ struct TailStreamParams {
     const float* ui;           // [B][3][2H][2W]
     float* out;                // [B][3][2H][2W]
     int B, H, W, nstrip, nband, band_h, clamp01;
+    // RESIZE: tap tables (as tup_resize_aa_fwd), ownership of output columns per strip / output rows per band, strip stride (LR
+    // columns; 60 minus the horizontal tap reach) and the LR rows a band runs past its end for the vertical taps
+    const int* ymin; const int* ysize; const float* yw; int KY;
+    const int* xmin; const int* xsize; const float* xw; int KX;
+    const int* oxb; const int* oyb;
+    int Ho, Wo, sc, ext;
 };
 
 // Neighbour exchange by DPP wave shifts, as volatile asm: the values are fetched where they are used (a handful of transient
@@ -48,6 +57,7 @@ TUP_DEVICE float from_right(float v) {    // lane l <- lane l + 1 (0 into lane 6
 
 // (the pointers are separate __restrict__ parameters: the weight reads inside the row loop stay scalar loads only while hipcc can
 // prove that the kernel's own stores do not alias them)
+template <bool RESIZE>
 __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     const float* __restrict__ x_arg, const float* __restrict__ wfu_arg, const float* __restrict__ bfu_arg,
     const float* __restrict__ wfc_arg, const float* __restrict__ bfc_arg, const float* __restrict__ ui_arg, float* __restrict__ out_arg,
@@ -61,6 +71,7 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     // would hoist all of them to the top of the stage and spill 200 VGPRs); waits are counted by hand.  The only barrier of the
     // kernel follows the copy.
     __shared__ __attribute__((aligned(16))) float wl[36 * 12 + 12 + 4];
+    __shared__ __attribute__((aligned(16))) float hb[RESIZE ? 4 : 1][3][128];          // RESIZE: one vertically filtered HR line per wave
     for (int i = threadIdx.x; i < 27 * 12; i += 256) wl[i] = wfu_arg[i];
     if (threadIdx.x < 27 * 4) wl[324 + threadIdx.x] = wfc_arg[threadIdx.x];
     if (threadIdx.x < 12) wl[432 + threadIdx.x] = bfu_arg[threadIdx.x];
@@ -71,10 +82,11 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     if (wid >= p.B * p.nband * p.nstrip) return;
     const int strip = wid % p.nstrip, band = (wid / p.nstrip) % p.nband, b = wid / (p.nstrip * p.nband);
     const int H = p.H, W = p.W, Hs = 2 * H, Ws = 2 * W;
-    const int xcol = strip * TS_COLS - 2 + lane;
+    const int xcol = strip * (RESIZE ? p.sc : TS_COLS) - 2 + lane;
     const bool colok = xcol >= 0 && xcol < W;
     const bool store_lane = lane >= 2 && lane < 2 + TS_COLS && xcol < W;
     const int y0 = band * p.band_h, y1 = min(y0 + p.band_h, H);
+    const int y_end = RESIZE ? min(y1 + p.ext, H) : y1;             // RESIZE: the rows under the vertical taps of the band's last output rows
     // every address = wave-uniform row pointer (SALU) + one per-lane element offset, clamped so that masked lanes stay in range
     // Buffer addressing: resource descriptor (the tensor) + wave-uniform byte offset of the row (SGPR, SALU arithmetic) + one per-lane
     // byte offset (VGPR, fixed for the whole kernel): no vector address arithmetic in the row loop.  The launcher refuses tensors
@@ -94,6 +106,43 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     // with a pending load in its other half makes the instruction wait for that load (vmcnt(0) in the middle of stage B).
     f32x2 xn[3];                    // [0] = LR row r + 2 of channel c, requested at the top of iteration r
     f32x2 un[1][3][2];              // upscaled_input (HR rows 2q, 2q+1): requested at the end of iteration q (stage C of q - 1 has read the previous rows), used in q + 1
+
+    // RESIZE state: the last six HR rows of the sums (slot = HR row % 6 = 2 (LR row % 3) + i), the lane's output columns of the
+    // two gather passes with their first tap (as an index into the wave's LDS line) and weights, the band's next output row
+    f32x2 VR[RESIZE ? 6 : 1][3];
+    int oxl[2] = {0, 0}, xi[2] = {0, 0};
+    bool hval[2] = {false, false};
+    float xwt[2][4] = {};
+    int oy = 0, oy_end = 0;
+    const int wv = threadIdx.x >> 6;
+    if constexpr (RESIZE) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) VR[k][c] = f32x2{0.f, 0.f};         // (an unwritten slot meets weight 0: it must not hold a NaN)
+        const int ox0 = p.oxb[strip], ox1 = p.oxb[strip + 1];
+        const int hx0 = 2 * (strip * p.sc - 2);                           // HR column of LDS index 0 (lane 0's first column)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ox = ox0 + lane + 64 * q;
+            hval[q] = ox < ox1;
+            oxl[q] = hval[q] ? ox : ox0;
+            xi[q] = hval[q] ? p.xmin[oxl[q]] - hx0 : 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xwt[q][t] = (hval[q] && t < p.KX) ? p.xw[oxl[q] * p.KX + t] : 0.f;
+        }
+        oy = p.oyb[band];
+        oy_end = p.oyb[band + 1];
+    }
+    int nym = 0, nyn = 0;                 // RESIZE: first tap row, tap count and weights of output row `oy` (wave-uniform)
+    float nyw[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_row_taps = [&](int row) __attribute__((always_inline)) {
+        const int rr = row < oy_end ? row : oy_end - 1;
+        nym = p.ymin[rr]; nyn = p.ysize[rr];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) nyw[a] = a < p.KY ? p.yw[rr * p.KY + a] : 0.f;
+    };
+    if constexpr (RESIZE) { if (oy < oy_end) fetch_row_taps(oy); }
 
     auto load_x_row = [&](int row, f32x2 (&dst)[3]) __attribute__((always_inline)) {
         const bool rok = row >= 0 && row < H;                     // wave-uniform
@@ -223,15 +272,57 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (store_lane) {
+        if constexpr (!RESIZE) {
+            if (store_lane) {
 #pragma unroll
-            for (int o = 0; o < 3; ++o)
+                for (int o = 0; o < 3; ++o)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f32x2 v = ac[i][o];
-                    if (p.clamp01) { v[0] = fminf(fmaxf(v[0], 0.f), 1.f); v[1] = fminf(fmaxf(v[1], 0.f), 1.f); }
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, vu, (((b * 3 + o) * Hs + 2 * q + i) * Ws) * 4, 0);
+                    for (int i = 0; i < 2; ++i) {
+                        f32x2 v = ac[i][o];
+                        if (p.clamp01) { v[0] = fminf(fmaxf(v[0], 0.f), 1.f); v[1] = fminf(fmaxf(v[1], 0.f), 1.f); }
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), ro, vu, (((b * 3 + o) * Hs + 2 * q + i) * Ws) * 4, 0);
+                    }
+            }
+        } else {
+            // HR rows 2q, 2q+1 enter the ring (q % 3 = SM); then every output row of this band whose last tap row now exists
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) VR[2 * SM + i][o] = ac[i][o];
+            while (oy < oy_end) {
+                const int ym = nym, yn = nyn;                          // this row's taps were fetched an emission ago (scalar loads:
+                if (ym + yn - 1 > 2 * q + 1) break;                    // their latency would otherwise sit in front of every row)
+                float ws[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // tap weights by ring slot (wave-uniform)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int sl = (ym + a) % 6;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) ws[k] = (sl == k && a < yn) ? nyw[a] : ws[k];
                 }
+                fetch_row_taps(oy + 1);
+                f32x2 vr[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    vr[c] = f32x2{ws[0], ws[0]} * VR[0][c];
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) vr[c] = __builtin_elementwise_fma(f32x2{ws[k], ws[k]}, VR[k][c], vr[c]);
+                    *reinterpret_cast<f32x2*>(&hb[wv][c][2 * lane]) = vr[c];
+                }
+#pragma unroll
+                for (int pq = 0; pq < 2; ++pq)
+                    if (hval[pq]) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            float o = xwt[pq][0] * hb[wv][c][xi[pq]];
+#pragma unroll
+                            for (int t = 1; t < 4; ++t) o = __builtin_fmaf(xwt[pq][t], hb[wv][c][xi[pq] + t], o);
+                            if (p.clamp01) o = fminf(fmaxf(o, 0.f), 1.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ro, (unsigned)oxl[pq] * 4u,
+                                                                  (((b * 3 + c) * p.Ho + oy) * p.Wo) * 4, 0);
+                        }
+                    }
+                ++oy;
+            }
         }
     };
 
@@ -263,13 +354,28 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     }
     int r = y0 - 1;
     iteration(r, 2); ++r;
-    while (r <= y1) {
-        iteration(r, 0); if (++r > y1) break;
-        iteration(r, 1); if (++r > y1) break;
+    while (r <= y_end) {
+        iteration(r, 0); if (++r > y_end) break;
+        iteration(r, 1); if (++r > y_end) break;
         iteration(r, 2); ++r;
     }
 }
 
+}  // namespace
+
+namespace {
+int launch_tail_stream(TailStreamParams& p, const float* x, const float* wfu_t, const float* bfu, const float* wfc_t, const float* bfc,
+                       const float* ui, float* out, bool resize, void* stream)
+{
+    const long long waves = (long long)p.B * p.nstrip * p.nband;
+    if (waves > (1ll << 30) || (long long)p.B * 3 * 4 * p.H * p.W >= (1ll << 29)) return (int)hipErrorInvalidValue;     // 32-bit byte offsets
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (resize) tail_stream_r2_kernel<true><<<grid, dim3(256), 0, s>>>(x, wfu_t, bfu, wfc_t, bfc, ui, out, p);
+    else tail_stream_r2_kernel<false><<<grid, dim3(256), 0, s>>>(x, wfu_t, bfu, wfc_t, bfc, ui, out, p);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
 }  // namespace
 
 // x fp32 [B][3][H][W]; wfu_t fp32 [27][12], bfu [12]; wfc_t fp32 [27][4], bfc [3] (packing.pack_planar_t);
@@ -279,7 +385,6 @@ extern "C" int tup_tail_stream_r2_fwd(const float* x, const float* wfu_t, const 
 {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     TailStreamParams p{};
-    p.x = x; p.wfu_t = wfu_t; p.bfu = bfu; p.wfc_t = wfc_t; p.bfc = bfc; p.ui = ui; p.out = out;
     p.B = B; p.H = H; p.W = W; p.clamp01 = clamp01;
     p.nstrip = (W + TS_COLS - 1) / TS_COLS;
     // bands: as many as fill the chip once at three waves per SIMD (256 CUs x 4 SIMDs x 3), each band a multiple of 3 rows and at
@@ -294,10 +399,30 @@ extern "C" int tup_tail_stream_r2_fwd(const float* x, const float* wfu_t, const 
         p.band_h = bh;
         p.nband = (H + bh - 1) / bh;
     }
-    const long long waves = (long long)B * p.nstrip * p.nband;
-    if (waves > (1ll << 30) || (long long)B * 3 * 4 * H * W >= (1ll << 29)) return (int)hipErrorInvalidValue;     // 32-bit byte offsets
-    tail_stream_r2_kernel<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        x, wfu_t, bfu, wfc_t, bfc, ui, out, p);
-    TUP_CHECK_LAUNCH();
-    return 0;
+    return launch_tail_stream(p, x, wfu_t, bfu, wfc_t, bfc, ui, out, false, stream);
+}
+
+// The same followed by the antialiased Resize to Ho x Wo (model.py:323-325) and the clamp: out fp32 [B][3][Ho][Wo].
+// Tap tables as tup_resize_aa_fwd (every tap count <= 4).  The caller fixes the decomposition and says who owns what:
+// sc = LR columns a strip advances by (<= 60 - ceil((max taps - 1) / 2)), band_h = LR rows per band (a multiple of 3), ext = LR rows a
+// band runs past its end (ceil((max taps - 1) / 2)); oxb int [nstrip + 1], oyb int [nband + 1]: strip s owns the output columns
+// [oxb[s], oxb[s+1]) = those whose first tap lies in its HR columns [2 s sc, 2 (s+1) sc), band k the output rows [oyb[k], oyb[k+1])
+// whose first tap lies in its HR rows [2 k band_h, 2 (k+1) band_h); nstrip = ceil(W / sc), nband = ceil(H / band_h).
+extern "C" int tup_tail_stream_r2_resize_fwd(const float* x, const float* wfu_t, const float* bfu, const float* wfc_t, const float* bfc,
+                                             const float* ui, float* out, const int* ymin, const int* ysize, const float* yw, int KY,
+                                             const int* xmin, const int* xsize, const float* xw, int KX, const int* oxb, const int* oyb,
+                                             int B, int H, int W, int Ho, int Wo, int sc, int band_h, int ext, int clamp01, void* stream)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    if (sc < 1 || sc > TS_COLS || band_h < 3 || band_h % 3 != 0 || ext < 0 || ext > 2 || Ho < 1 || Wo < 1 || KX < 1 || KY < 1)
+        return (int)hipErrorInvalidValue;
+    if ((long long)B * 3 * Ho * Wo >= (1ll << 29)) return (int)hipErrorInvalidValue;
+    TailStreamParams p{};
+    p.B = B; p.H = H; p.W = W; p.clamp01 = clamp01;
+    p.nstrip = (W + sc - 1) / sc;
+    p.band_h = band_h;
+    p.nband = (H + band_h - 1) / band_h;
+    p.ymin = ymin; p.ysize = ysize; p.yw = yw; p.KY = KY; p.xmin = xmin; p.xsize = xsize; p.xw = xw; p.KX = KX;
+    p.oxb = oxb; p.oyb = oyb; p.Ho = Ho; p.Wo = Wo; p.sc = sc; p.ext = ext;
+    return launch_tail_stream(p, x, wfu_t, bfu, wfc_t, bfc, ui, out, true, stream);
 }

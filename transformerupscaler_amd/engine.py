@@ -154,8 +154,9 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
         if stream_tail and fu[li][1] == 2 and "tail.wfu_t" in pk:
             with _stage("tail"):
                 out = ops.tail_stream_r2(t, pk["tail.wfu_t"], pk[f"fu.{li}.b"], pk["tail.wfc_t"], pk["fuc.b"], upscaled_input,
-                                         clamp=not needs_resize)
-                if needs_resize:
+                                         clamp=True, out_hw=tuple(res_out) if needs_resize else None)
+                if out is None:        # a Resize with more than 4 taps per output: pre-resize sums, then the separable Resize kernel
+                    out = ops.tail_stream_r2(t, pk["tail.wfu_t"], pk[f"fu.{li}.b"], pk["tail.wfc_t"], pk["fuc.b"], upscaled_input, clamp=False)
                     out = ops.resize_aa(out, tuple(res_out), clamp=True)
             return out
         with _stage("tail"):

@@ -179,13 +179,60 @@ def tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True):
     return out
 
 
-def tail_stream_r2(x, wfu_t, bfu, wfc_t, bfc, ui, clamp=True):
-    """Last final_upscale stage (r = 2) + final_upscale_conv + "+ upscaled_input" [+ clamp] at the HR size, streaming kernel."""
+def _tail_stream_plan(device, B, H, W, Ho, Wo):
+    """Decomposition of the fused streaming tail + Resize (csrc/tail_stream.hip, RESIZE = true): strip stride, band height, the
+    output columns / rows each strip / band owns.  None when a tap table has more than 4 taps (then the Resize runs as its own kernel)."""
+    key = (str(device), "tail_stream", B, H, W, Ho, Wo)
+    if key not in _TAP_CACHE:
+        from .resize_taps import aa_taps
+        ylo, yn, yw, ky = aa_taps(2 * H, Ho)
+        xlo, xn, xw, kx = aa_taps(2 * W, Wo)
+        plan = None
+        if int(yn.max()) <= 4 and int(xn.max()) <= 4:
+            sc = 60 - (int(xn.max()) - 1 + 1) // 2
+            ext = (int(yn.max()) - 1 + 1) // 2
+            nstrip = (W + sc - 1) // sc
+            nb = max(1, (256 * 4 * 2) // max(1, B * nstrip))            # fill the chip once at two waves per SIMD
+            bh = max(12, ((H + nb - 1) // nb + 2) // 3 * 3)
+            nband = (H + bh - 1) // bh
+            oxb = np.searchsorted(xlo, 2 * sc * np.arange(nstrip + 1), side="left").astype(np.int32)
+            oyb = np.searchsorted(ylo, 2 * bh * np.arange(nband + 1), side="left").astype(np.int32)
+            oxb[-1], oyb[-1] = Wo, Ho
+            ok = True
+            for s_ in range(nstrip):           # every owned column's taps inside the strip's 120 valid HR columns, <= 128 gathered
+                a, b_ = int(oxb[s_]), int(oxb[s_ + 1])
+                if b_ > a:
+                    ok &= bool((xlo[a:b_] + xn[a:b_]).max() <= 2 * s_ * sc + 120) and b_ - a <= 128
+            for k_ in range(nband):            # every owned row's taps inside the rows the band computes
+                a, b_ = int(oyb[k_]), int(oyb[k_ + 1])
+                if b_ > a:
+                    ok &= bool((ylo[a:b_] + yn[a:b_]).max() <= 2 * min(H, (k_ + 1) * bh + ext))
+            if ok:
+                t = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+                plan = (t(ylo), t(yn), t(yw), ky, t(xlo), t(xn), t(xw), kx, t(oxb), t(oyb), sc, bh, ext)
+        _TAP_CACHE[key] = plan
+    return _TAP_CACHE[key]
+
+
+def tail_stream_r2(x, wfu_t, bfu, wfc_t, bfc, ui, clamp=True, out_hw=None):
+    """Last final_upscale stage (r = 2) + final_upscale_conv + "+ upscaled_input" [+ antialiased Resize to out_hw] [+ clamp],
+    streaming kernel.  Returns None when out_hw needs a Resize whose tap tables the fused kernel does not take (> 4 taps)."""
     B, C, H, W = x.shape
-    out = torch.empty((B, 3, 2 * H, 2 * W), dtype=F32, device=x.device)
-    _lib.call("tup_tail_stream_r2_fwd", _chk(x, F32, (B, 3, H, W), "x"), _chk(wfu_t, F32, (27, 12), "wfu_t"), _chk(bfu, F32, (12,), "bfu"),
-              _chk(wfc_t, F32, (27, 4), "wfc_t"), _chk(bfc, F32, (3,), "bfc"), _chk(ui, F32, (B, 3, 2 * H, 2 * W), "ui"),
-              out.data_ptr(), B, H, W, int(clamp), _stream())
+    args = (_chk(x, F32, (B, 3, H, W), "x"), _chk(wfu_t, F32, (27, 12), "wfu_t"), _chk(bfu, F32, (12,), "bfu"),
+            _chk(wfc_t, F32, (27, 4), "wfc_t"), _chk(bfc, F32, (3,), "bfc"), _chk(ui, F32, (B, 3, 2 * H, 2 * W), "ui"))
+    if out_hw is None or tuple(out_hw) == (2 * H, 2 * W):
+        out = torch.empty((B, 3, 2 * H, 2 * W), dtype=F32, device=x.device)
+        _lib.call("tup_tail_stream_r2_fwd", *args, out.data_ptr(), B, H, W, int(clamp), _stream())
+        return out
+    Ho, Wo = int(out_hw[0]), int(out_hw[1])
+    plan = _tail_stream_plan(x.device, B, H, W, Ho, Wo)
+    if plan is None:
+        return None
+    ylo, yn, yw, ky, xlo, xn, xw, kx, oxb, oyb, sc, bh, ext = plan
+    out = torch.empty((B, 3, Ho, Wo), dtype=F32, device=x.device)
+    _lib.call("tup_tail_stream_r2_resize_fwd", *args, out.data_ptr(), ylo.data_ptr(), yn.data_ptr(), yw.data_ptr(), ky,
+              xlo.data_ptr(), xn.data_ptr(), xw.data_ptr(), kx, oxb.data_ptr(), oyb.data_ptr(), B, H, W, Ho, Wo, sc, bh, ext,
+              int(clamp), _stream())
     return out
 
 

@@ -131,8 +131,10 @@ int tup_ln_gemm_fwd(const float* x, const float* gamma, const float* beta, const
                     const float* bias, void* out, int M, int N, void* stream);
 
 /* Inference fusion of the MLP half of a block: x += mlp.2(GELU(mlp.0(norm2(x)))) (model.py:144-151,168-171);
- * the [M][768] hidden tensor stays in registers.  x fp32 [M][192] in place; w1 bf16 [768][192] (rows permuted per
- * 64-group AND columns in the kernel's K order, packing.pack_fc1_fused), w2 bf16 [192][768] (rows permuted per 64-group). */
+ * the [M][768] hidden tensor stays in registers.  x fp32 [M][192] in place; w1 bf16 [768][192] = mlp.0.weight / 4 (rows
+ * permuted per 64-group AND columns in the kernel's K order) and b1 = mlp.0.bias / 4 (packing.pack_fc1_fused_q: exact powers of
+ * two), w2 FP16 [192][768] = 4 mlp.2.weight (rows permuted per 64-group, packing.pack_fc2_h4): erf-GELU (nn.GELU(), model.py:148)
+ * is evaluated in packed fp16 on x / 4 and FC2 runs on the fp16 MFMA, the factors of 4 cancel. */
 int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                       const void* w2, const float* b2, int M, void* stream);
 
@@ -396,17 +398,6 @@ int tup_resize_u8_cols(const void* src, void* dst_u8, float* dst_f32, const int*
  * disappear.  x fp32 [64*nwin][192] in place; table: HOST array [nblk][13] of device pointers, per block the arguments of
  * tup_fused_block_fwd after x in that order and packing. */
 int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
-
-/* nblk consecutive WindowTransformerBlocks in ONE launch with ONE WAVE PER WINDOW (64 tokens = four MFMA token tiles per wave,
- * one 256-thread workgroup per CU with the whole register file): replaces the loop `for block in self.window_blocks`,
- * model.py:288-289, with WindowTransformerBlock.forward :153-172 and WindowAttention.forward :104-133 inside.  K and V never
- * leave the registers (V comes out of the qkv product transposed by swapping its operands), every LDS weight fragment feeds 4
- * MFMAs, the weight stream is shared by 256 tokens; a window never meets another window, so its wave carries it through all
- * nblk blocks and HBM sees x once in and once out.
- * x fp32 [64*nwin][192] in window order, updated in place.  table: HOST array [nblk][13] (nblk <= 8) of device pointers,
- * per block the arguments of tup_fused_block_fwd after x, in that order and packing
- * (gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2); it is copied into the kernel arguments. */
-int tup_fused_blocks64_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
 
 /* Re-packing the weights after an optimizer step (training; replaces the torch index / permute / cat / cast calls of
  * packing.py that follow reference train.py:139 `optimizer.step()`): dst[i] = map[i] < 0 ? 0 : concat(src[0..nparam-1])[map[i]].

@@ -1,4 +1,4 @@
-"""Per-phase cycle shares of the one-wave-per-window block kernel (diagnostic build, TUP_B32_STAMPS=1)."""
+"""Per-phase cycle shares of the whole-block kernel (diagnostic build, TUP_B32_STAMPS=1)."""
 import os, sys, ctypes
 os.environ["TUP_B32_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ for _ in range(3):
     if six:
         ops.fused_blocks32(x.clone(), table6)
     else:
-        ops.fused_block(x.clone(), *args, tokens_per_wave=32)
+        ops.fused_block(x.clone(), *args)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * (8 * 4 * 16))()

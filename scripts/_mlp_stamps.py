@@ -7,7 +7,7 @@ M = 122880
 x = torch.randn(M, 192, device="cuda")
 gm = torch.ones(192, device="cuda"); bt = torch.zeros(192, device="cuda")
 w1 = (torch.randn(768, 192, device="cuda") * 0.05).to(torch.bfloat16); b1 = torch.zeros(768, device="cuda")
-w2 = (torch.randn(192, 768, device="cuda") * 0.05).to(torch.bfloat16); b2 = torch.zeros(192, device="cuda")
+w2 = (torch.randn(192, 768, device="cuda") * 0.05).to(torch.float16); b2 = torch.zeros(192, device="cuda")
 for _ in range(3):
     ops.fused_mlp(x, gm, bt, w1, b1, w2, b2)
 torch.cuda.synchronize()

@@ -16,28 +16,17 @@ x0 = raw["x"].to("cuda")
 arr, nblk, keep = ops.block_table([tuple(args)] * 6)
 P, I = ctypes.c_void_p, ctypes.c_int
 runs = {}
-wh_perm = args[2]                                   # as packing.pack_qkv_heads packs it now (K columns in accumulator order)
-wh_nat = ops._wh_natural_k(wh_perm)                 # libraries built before that change: name=path@natural
+wh_perm = args[2]
 keep = [keep]
-from transformerupscaler_amd import packing
-# libraries built with -DTUP_FA_GELU16=1 (name=path@gelu16): mlp.0 scaled by 1/4 (exact), mlp.2 as 4 W2 in fp16
-args16 = list(args)
-args16[9] = packing.pack_fc1_fused(raw["w1"] * 0.25).to("cuda")
-args16[10] = (raw["b1"] * 0.25).to("cuda")
-args16[11] = packing.perm_rows64(raw["w2"] * 4.0).contiguous().to(torch.float16).view(torch.bfloat16).to("cuda")      # fp16 bits, bf16 label (the table checks dtypes)
 for name, path in libs.items():
     path, _, flag = path.partition("@")
-    natural = flag == "natural"
-    args = args16 if flag == "gelu16" else args_bf16
     L = ctypes.CDLL(os.path.join(root, path))
     L.tup_fused_block_fwd.argtypes = [P] * 14 + [I, P]
     ptrs = [a.data_ptr() for a in args]
-    if natural:
-        ptrs[2] = wh_nat.data_ptr()
     runs[name + "/6 launches"] = (lambda x, L=L, ptrs=ptrs: [L.tup_fused_block_fwd(x.data_ptr(), *ptrs, nwin, None) for _ in range(6)])
     if hasattr(L, "tup_fused_blocks32_fwd"):
         L.tup_fused_blocks32_fwd.argtypes = [P, P, I, I, P]
-        tab = ops.block_table([tuple(args[:2]) + (wh_nat if natural else wh_perm,) + tuple(args[3:])] * 6)
+        tab = ops.block_table([tuple(args)] * 6)
         keep.append(tab)
         runs[name + "/1 launch"] = (lambda x, L=L, tab=tab: L.tup_fused_blocks32_fwd(x.data_ptr(), tab[0], 6, nwin, None))
 x = x0.clone()

@@ -12,14 +12,13 @@ dev = "cuda"
 import test_hip_kernels as T
 raw, args = T._block_operands(dev, nwin)
 x0 = raw["x"].to(dev)
-variants = {"block32": 32, "blocks32x6": -1, "block64": 64, "blocks64x6": 0}
+variants = {"block x6 launches": 32, "blocks32, one launch": -1}
 table6 = ops.block_table([tuple(args)] * 6)
-table6_64 = ops.block_table([tuple(args)] * 6, natural_k=True)
 xs = {k: x0.clone() for k in variants}
 times = {k: [] for k in variants}
 for k, tpw in variants.items():                       # warm-up
     for _ in range(3):
-        ops.fused_block(xs[k], *args, tokens_per_wave=tpw if tpw > 0 else 32)
+        ops.fused_block(xs[k], *args)
 torch.cuda.synchronize()
 for r in range(rounds):
     for k, tpw in variants.items():
@@ -28,11 +27,9 @@ for r in range(rounds):
         s.record()
         if tpw == -1:
             ops.fused_blocks32(xs[k], table6)
-        elif tpw == 0:
-            ops.fused_blocks64(xs[k], table6_64)          # the 6 blocks of a forward in one launch
         else:
             for _ in range(6):                            # ... as 6 launches
-                ops.fused_block(xs[k], *args, tokens_per_wave=tpw)
+                ops.fused_block(xs[k], *args)
         e.record(); torch.cuda.synchronize()
         times[k].append(s.elapsed_time(e) / 6 * 1e3)
 gf = 86.1e9 / 6 * nwin / 240

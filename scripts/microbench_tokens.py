@@ -19,12 +19,14 @@ x = torch.randn((M, 192), device=dev)
 gm, bt = torch.ones(192, device=dev), torch.zeros(192, device=dev)
 w1raw = torch.randn(768, 192) * 0.05
 w1, b1 = packing.pack_linear(w1raw).to(dev), torch.zeros(768, device=dev)
-w1f = packing.pack_fc1_fused(w1raw).to(dev)
-w2, b2 = packing.pack_linear(torch.randn(192, 768) * 0.05).to(dev), torch.zeros(192, device=dev)
+w1f, b1q = [t.to(dev) for t in packing.pack_fc1_fused_q(w1raw, torch.zeros(768))]
+w2raw = torch.randn(192, 768) * 0.05
+w2, b2 = packing.pack_linear(w2raw).to(dev), torch.zeros(192, device=dev)
+w2h = packing.pack_fc2_h4(w2raw).to(dev)
 wq, bq = packing.pack_linear(torch.randn(576, 192) * 0.05).to(dev), torch.zeros(576, device=dev)
 wp, bp = packing.pack_linear(torch.randn(192, 192) * 0.05).to(dev), torch.zeros(192, device=dev)
 frag = ops.relpos_bias_expand(torch.zeros(225, 12, device=dev))
-print("fused_mlp   %.1f us" % timeit(lambda: ops.fused_mlp(x, gm, bt, w1f, b1, w2, b2)))
+print("fused_mlp   %.1f us" % timeit(lambda: ops.fused_mlp(x, gm, bt, w1f, b1q, w2h, b2)))
 def unfused_mlp():
     y = ops.layernorm(x, gm, bt); h = ops.gemm_tokens(y, w1, b1, "gelu"); ops.gemm_tokens(h, w2, b2, "res", res=x, out=x)
 print("unfused_mlp %.1f us" % timeit(unfused_mlp))

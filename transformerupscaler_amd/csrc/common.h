@@ -153,6 +153,60 @@ TUP_DEVICE void gelu_erf2_batch(f32x2 (&x)[N]) {
     for (int i = 0; i < N; ++i) x[i] = x[i] * (xc[i] * q[i] + 0.5f);
 }
 
+// ---- GELU in packed fp16, for the fused inference MLPs (fused_attn.hip, fused_blocks.hip) ----
+// mlp.0's weight and bias reach those kernels scaled by 1/4 (exact in bf16 / fp32: packing.pack_fc1_fused_q), so FC1's accumulators
+// hold x' = x / 4.  gelu(x) / 4 = x' (0.5 + xc R(xc^2 - 0.5)), xc = clamp(x', +-1) [i.e. x clamped at +-4], R of degree 6 fitted to
+// (Phi(4 x') - 0.5) / x' with weight x^2 and the clamped tail pinned (C R(C^2 - 0.5) = 0.5); the hidden tile stays fp16 and FC2 runs
+// on v_mfma_f32_16x16x32_f16 against 4 W2 in fp16 (packing.pack_fc2_h4), so the three factors of 4 cancel exactly.
+// Why fp16: a v_pk_*_f16 instruction costs ONE VALU issue for two values where v_pk_*_f32 costs two and stalls beside MFMAs
+// (scripts/microbench_valu.hip: 12.8 vs 29.2 cycles per instruction next to a wave streaming MFMAs); 12 instructions per value
+// pair including the conversion.  Accuracy, fp16 arithmetic emulated over x in [-6, 6] and N(0, 1.5): rms |error| 4.6e-4, max 5.1e-3
+// -- the bf16 hidden tile it replaces has rms 2.4e-3, max 1.6e-2 (the polynomial's fp16 rounding is below the bf16 rounding of the
+// value it used to be stored as).  The scaling keeps every coefficient of R between 0.67 and 2.2 (in u = xc^2 alone the high
+// orders underflow fp16) and the Horner chain well conditioned (|s| <= 0.5).
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+template <int N>
+TUP_DEVICE void gelu16_batch(h2 (&x)[N]) {
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    h2 xc[N], sv[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        xc[i] = __builtin_elementwise_min(__builtin_elementwise_max(x[i], -one), one);
+        sv[i] = __builtin_elementwise_fma(xc[i], xc[i], h2{(_Float16)-0.5f, (_Float16)-0.5f});
+        q[i] = __builtin_elementwise_fma(sv[i], h2{(_Float16)1.51615563f, (_Float16)1.51615563f}, h2{(_Float16)-2.11659751f, (_Float16)-2.11659751f});
+    }
+    constexpr float C[5] = {1.54543088f, -1.13520344f, 0.88632128f, -0.6753973f, 0.70388307f};
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(q[i], sv[i], h2{(_Float16)C[k], (_Float16)C[k]});
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = x[i] * __builtin_elementwise_fma(xc[i], q[i], h2{(_Float16)0.5f, (_Float16)0.5f});
+}
+// FC1 accumulators (x / 4, fp32) of both token tiles -> the fp16 hidden fragments gelu(x) / 4 (the B operand of FC2)
+TUP_DEVICE void gelu16_fragments(const f32x4 (&acc1)[2][2], bf16x8 (&hfr)[2]) {
+    h2 hv[8];                          // both token tiles in lockstep: 8 independent chains
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            hv[tg * 4 + hh * 2 + 0] = __builtin_convertvector(f32x2{acc1[tg][hh][0], acc1[tg][hh][1]}, h2);
+            hv[tg * 4 + hh * 2 + 1] = __builtin_convertvector(f32x2{acc1[tg][hh][2], acc1[tg][hh][3]}, h2);
+        }
+    gelu16_batch<8>(hv);
+#pragma unroll
+    for (int tg = 0; tg < 2; ++tg) {
+        u32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = __builtin_bit_cast(uint32_t, hv[tg * 4 + q]);
+        hfr[tg] = __builtin_bit_cast(bf16x8, pk);          // fp16 bits in the kernels' 16-byte fragment type
+    }
+}
+TUP_DEVICE f32x4 mfma16x16x32_f16(bf16x8 a, bf16x8 b, f32x4 c) {         // operands: fp16 bits carried as 16-byte fragments
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+
 // nn.GELU() default = exact erf form (reference model.py:148)
 TUP_DEVICE f32x2 gelu_erf2(f32x2 x) {
     f32x2 v[1] = {x};
@@ -169,6 +223,9 @@ TUP_DEVICE float gelu_erf_grad(float x) {
 // The same function is evaluated by the forward and the backward kernels (nothing is stored) and by the
 // CPU checker in tests (tests/test_hip_dropout.py), bit for bit.
 TUP_DEVICE uint32_t drop_hash(uint32_t seed, uint32_t idx) {
+#ifdef TUP_CHEAP_HASH          // timing experiment only: what the hash costs the attention kernels
+    return idx * 0x9E3779B1u + seed;
+#endif
     uint32_t h = idx * 0x9E3779B1u + seed;
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;

@@ -21,9 +21,6 @@
 #ifndef TUP_FA_FRAG
 #define TUP_FA_FRAG 0
 #endif
-#ifndef TUP_FA_GELU16
-#define TUP_FA_GELU16 0
-#endif
 
 namespace {
 
@@ -65,37 +62,6 @@ struct MlpArgs {
     const bf16_t* w1; const float* b1; const bf16_t* w2; const float* b2;
 };
 constexpr int HID = 768;
-// GELU in packed fp16 (TUP_FA_GELU16): mlp.0's weight and bias arrive scaled by 1/4 (exact in bf16 / fp32), so FC1's accumulators
-// hold x' = x / 4; gelu(x) / 4 = x' (0.5 + xc R(xc^2 - 0.5)), xc = clamp(x', +-1), R of degree 6; the hidden tile stays fp16 and
-// FC2 runs on v_mfma_f32_16x16x32_f16 against 4 W2 in fp16.  A packed-fp16 instruction costs one VALU issue for two values
-// where v_pk_*_f32 costs two and stalls beside MFMAs (scripts/microbench_valu.hip).
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-TUP_DEVICE f32x4 mfma_fc2(bf16x8 a, bf16x8 b, f32x4 c) {
-#if TUP_FA_GELU16
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-#else
-    return mfma16x16x32(a, b, c);
-#endif
-}
-template <int N>
-TUP_DEVICE void gelu16_batch(h2 (&x)[N]) {
-    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-    h2 xc[N], sv[N], q[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        xc[i] = __builtin_elementwise_min(__builtin_elementwise_max(x[i], -one), one);
-        sv[i] = __builtin_elementwise_fma(xc[i], xc[i], h2{(_Float16)-0.5f, (_Float16)-0.5f});
-        q[i] = __builtin_elementwise_fma(sv[i], h2{(_Float16)1.51615563f, (_Float16)1.51615563f}, h2{(_Float16)-2.11659751f, (_Float16)-2.11659751f});
-    }
-    constexpr float C[5] = {1.54543088f, -1.13520344f, 0.88632128f, -0.6753973f, 0.70388307f};
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-#pragma unroll
-        for (int i = 0; i < N; ++i) q[i] = __builtin_elementwise_fma(q[i], sv[i], h2{(_Float16)C[k], (_Float16)C[k]});
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = x[i] * __builtin_elementwise_fma(xc[i], q[i], h2{(_Float16)0.5f, (_Float16)0.5f});
-}
 // parameters of one WindowTransformerBlock; the table is a kernel argument BY VALUE (pointer fields of a kernel argument are
 // global pointers to hipcc; pointers read from memory would be generic and every load through them a flat_load)
 struct BlockPtrs {
@@ -639,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                         for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
                             for (int hh = 0; hh < 2; ++hh)
-                                acc1[tg][hh] = mfma16x16x32(wf[cur][hh], tf2[tg][step], (TUP_FA_GELU16 && step == 0) ? bb[hh] : acc1[tg][hh]);
+                                acc1[tg][hh] = mfma16x16x32(wf[cur][hh], tf2[tg][step], step == 0 ? bb[hh] : acc1[tg][hh]);
                         __builtin_amdgcn_sched_barrier(0);
                         if (s == 0 && more) { dma_w1_piece(j + 1, j & 1, step); __builtin_amdgcn_sched_barrier(0); }
                     }
@@ -660,41 +626,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                     for (int n = 0; n < 8; ++n) w2f[n] = w2rd(n);
                     __builtin_amdgcn_sched_barrier(0);
                     bf16x8 hfr[2];
-#if TUP_FA_GELU16
-                    {
-                        h2 hv[8];                      // both token tiles in lockstep: 8 independent chains
-#pragma unroll
-                        for (int tg = 0; tg < 2; ++tg)
-#pragma unroll
-                            for (int hh = 0; hh < 2; ++hh) {
-                                hv[tg * 4 + hh * 2 + 0] = __builtin_convertvector(f32x2{acc1[tg][hh][0], acc1[tg][hh][1]}, h2);
-                                hv[tg * 4 + hh * 2 + 1] = __builtin_convertvector(f32x2{acc1[tg][hh][2], acc1[tg][hh][3]}, h2);
-                            }
-                        gelu16_batch<8>(hv);
-#pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) {
-                            u32x4 pk;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) pk[q] = __builtin_bit_cast(uint32_t, hv[tg * 4 + q]);
-                            hfr[tg] = __builtin_bit_cast(bf16x8, pk);
-                        }
-                    }
-#else
-#pragma unroll
-                    for (int tg = 0; tg < 2; ++tg) {
-                        f32x2 gv[4];
-#pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
-                            gv[hh * 2 + 0] = f32x2{acc1[tg][hh][0] + bb[hh][0], acc1[tg][hh][1] + bb[hh][1]};
-                            gv[hh * 2 + 1] = f32x2{acc1[tg][hh][2] + bb[hh][2], acc1[tg][hh][3] + bb[hh][3]};
-                        }
-                        gelu_erf2_batch<4>(gv);
-                        u32x4 pk;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pk[q] = pack_bf16x2(gv[q][0], gv[q][1]);
-                        hfr[tg] = __builtin_bit_cast(bf16x8, pk);
-                    }
-#endif
+                    gelu16_fragments(acc1, hfr);          // fp16: gelu(x) / 4 (common.h)
                     __builtin_amdgcn_sched_barrier(0);
                     B32_STAMP(P_GELU);
                     lds_wait<4>();
@@ -702,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma_fc2(w2f[n], hfr[tg], acc2[tg][n]);
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][n]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) w2f[n] = w2rd(8 + n);
@@ -711,14 +643,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                     for (int n = 4; n < 8; ++n)
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma_fc2(w2f[n], hfr[tg], acc2[tg][n]);
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][n]);
                     __builtin_amdgcn_sched_barrier(0);
                     lds_wait<0>();
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][8 + n] = mfma_fc2(w2f[n], hfr[tg], acc2[tg][8 + n]);
+                        for (int tg = 0; tg < 2; ++tg) acc2[tg][8 + n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][8 + n]);
                     __builtin_amdgcn_sched_barrier(0);
                     B32_STAMP(P_FC2);
                 }

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
                 for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
-                        if ((ABL & 2) == 0 || step == 0) acc1[tg][h] = mfma16x16x32(wf[cur][h], tf[tg][step], acc1[tg][h]);
+                        if ((ABL & 2) == 0 || step == 0) acc1[tg][h] = mfma16x16x32(wf[cur][h], tf[tg][step], step == 0 ? bb[h] : acc1[tg][h]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (s == 0 && more) { dma_w1_piece(j + 1, (j + 1) & 1, step); __builtin_amdgcn_sched_barrier(0); }
             }
@@ -213,20 +213,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             for (int n = 0; n < 8; ++n) w2f[n] = lds_read_b128_asm(w2addr(n));
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 hf[2];
-#pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
-                f32x2 gv[4];           // [h][pair]: 4 independent polynomial chains advanced in lockstep
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    gv[h * 2 + 0] = f32x2{acc1[tg][h][0] + bb[h][0], acc1[tg][h][1] + bb[h][1]};
-                    gv[h * 2 + 1] = f32x2{acc1[tg][h][2] + bb[h][2], acc1[tg][h][3] + bb[h][3]};
-                }
-                if ((ABL & 1) == 0) gelu_erf2_batch<4>(gv);
-                u32x4 pk;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pk[q] = pack_bf16x2(gv[q][0], gv[q][1]);
-                hf[tg] = __builtin_bit_cast(bf16x8, pk);
-            }
+            gelu16_fragments(acc1, hf);          // fp16: gelu(x) / 4; acc1 already holds x / 4 incl. the bias (common.h)
             __builtin_amdgcn_sched_barrier(0);
             lds_wait<4>();
             if (j < 3) stamp();    // GELU done
@@ -235,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int tg = 0; tg < 2; ++tg)
-                    if ((ABL & 4) == 0 || n == 0) acc2[tg][n] = mfma16x16x32(w2f[n], hf[tg], acc2[tg][n]);
+                    if ((ABL & 4) == 0 || n == 0) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hf[tg], acc2[tg][n]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n = 0; n < 4; ++n) w2f[n] = lds_read_b128_asm(w2addr(8 + n));      // operands above were read at issue
@@ -245,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             for (int n = 4; n < 8; ++n)
 #pragma unroll
                 for (int tg = 0; tg < 2; ++tg)
-                    if ((ABL & 4) == 0) acc2[tg][n] = mfma16x16x32(w2f[n], hf[tg], acc2[tg][n]);
+                    if ((ABL & 4) == 0) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hf[tg], acc2[tg][n]);
             __builtin_amdgcn_sched_barrier(0);
             lds_wait<0>();
             __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int tg = 0; tg < 2; ++tg)
-                    if ((ABL & 4) == 0) acc2[tg][8 + n] = mfma16x16x32(w2f[n], hf[tg], acc2[tg][8 + n]);
+                    if ((ABL & 4) == 0) acc2[tg][8 + n] = mfma16x16x32_f16(w2f[n], hf[tg], acc2[tg][8 + n]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -278,8 +265,9 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
 
 }  // namespace
 
-// x fp32 [M][192] updated in place: x += W2 GELU(W1 LN(x) + b1) + b2.  w1 bf16 [768][192], w2 bf16 [192][768]
-// (both with rows permuted per 64-group, packing.pack_linear), biases / LayerNorm parameters fp32.
+// x fp32 [M][192] updated in place: x += W2 GELU(W1 LN(x) + b1) + b2.  w1 bf16 [768][192] = mlp.0.weight / 4 and b1 = mlp.0.bias / 4
+// (packing.pack_fc1_fused_q), w2 FP16 [192][768] = 4 mlp.2.weight (packing.pack_fc2_h4): the GELU runs in packed fp16 on x / 4
+// and FC2 on the fp16 MFMA (common.h, gelu16_batch); rows permuted per 64-group, other biases / LayerNorm parameters fp32.
 extern "C" int tup_fused_mlp_fwd(float* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                                  const void* w2, const float* b2, int M, void* stream)
 {

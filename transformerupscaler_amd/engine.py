@@ -56,26 +56,25 @@ stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the 
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and blocks_in_one_launch:
-        # all six blocks in ONE launch (csrc/fused_attn.hip, or fused_block64.hip with one wave per window)
+        # all six blocks in ONE launch (csrc/fused_attn.hip)
         table = ops.block_table([(pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
                                   pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
-                                  pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)],
-                                natural_k=ops.block_tokens_per_wave == 64)
-        return ops.fused_blocks64(x, table) if ops.block_tokens_per_wave == 64 else ops.fused_blocks32(x, table)
+                                  pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"], pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)])
+        return ops.fused_blocks32(x, table)
     for i in range(BLOCKS):
         qkv = None
         if fuse_blocks and fuse_attention >= 3 and capture is None and f"b{i}.proj.wpp" in pk:
             # the whole block in one kernel: the residual stream of a token tile stays in registers between the halves
             ops.fused_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
                             pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
-                            pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"], pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
+                            pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"], pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"])
             continue
         if fuse_blocks and fuse_attention == 2 and capture is None and f"b{i}.proj.wpp" in pk:
             # the whole attention half in one kernel, in place: neither the qkv nor the attention-output tensor exists
             ops.fused_attn_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
                                  pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"])
-            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"],
-                          pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
+            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"],
+                          pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"])
             continue
         if fuse_blocks and fuse_attention and capture is None and f"b{i}.qkv.wh" in pk:
             # norm1 + qkv + attention core in one kernel (the qkv tensor never exists)
@@ -88,9 +87,9 @@ def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags,
                 qkv = ops.gemm_tokens(y, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
             att = ops.window_attn(qkv, bias_frags[i])
         ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=x, out=x)
-        if fuse_blocks and f"b{i}.fc1.wf" in pk:
-            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wf"], pk[f"b{i}.fc1.b"],
-                          pk[f"b{i}.fc2.w"], pk[f"b{i}.fc2.b"])
+        if fuse_blocks and f"b{i}.fc1.wfq" in pk:
+            ops.fused_mlp(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"],
+                          pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"])
         else:
             y = ops.layernorm(x, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"])
             hid = ops.gemm_tokens(y, pk[f"b{i}.fc1.w"], pk[f"b{i}.fc1.b"], "gelu")

@@ -326,23 +326,19 @@ def fused_attn_block(x, gamma, beta, wh, bh, bias_frag, wproj, bproj):
     return x
 
 
-# which whole-block kernel runs: 32 = two waves per window, two workgroups per CU, one launch per block (fused_attn.hip; the
-# faster one: 198 vs 243 us per block at 1,920 windows, scripts/microbench_block.py); 64 = one wave per window, one workgroup
-# per CU, all blocks in one launch (fused_block64.hip; kept as the measured alternative)
-block_tokens_per_wave = int(os.environ.get("TUP_BLOCK_TOKENS_PER_WAVE", "32"))
+F16 = torch.float16
 
 
-def block_table(blocks, natural_k=False):
-    """Pointer table for tup_fused_blocks32_fwd / tup_fused_blocks64_fwd (natural_k=True): `blocks` = per block the 13 tensors (gamma1, beta1, wh, bh, bias_frag, wproj,
-    bproj, gamma2, beta2, w1, b1, w2, b2), validated here.  Returns (ctypes array [nblk*13] of device pointers, nblk, the tensors
-    -- kept alive by the caller holding the tuple)."""
+def block_table(blocks):
+    """Pointer table for tup_fused_blocks32_fwd: `blocks` = per block the 13 tensors (gamma1, beta1, wh, bh, bias_frag, wproj,
+    bproj, gamma2, beta2, w1 [= W1 / 4, packing.pack_fc1_fused_q], b1 [= b1 / 4], w2 [= 4 W2 in fp16, packing.pack_fc2_h4], b2),
+    validated here.  Returns (ctypes array [nblk*13] of device pointers, nblk, the tensors -- kept alive by the caller holding
+    the tuple)."""
     import ctypes
     shapes = [(F32, (192,)), (F32, (192,)), (BF16, (12, 64, 192)), (F32, (12, 48)), (F32, (12, 4, 4, 64, 4)), (BF16, (192, 192)),
-              (F32, (192,)), (F32, (192,)), (F32, (192,)), (BF16, (768, 192)), (F32, (768,)), (BF16, (192, 768)), (F32, (192,))]
+              (F32, (192,)), (F32, (192,)), (F32, (192,)), (BF16, (768, 192)), (F32, (768,)), (F16, (192, 768)), (F32, (192,))]
     if not 1 <= len(blocks) <= 8:
         raise ValueError("1..8 blocks per launch")
-    if natural_k:       # for tup_fused_blocks64_fwd: qkv head weights with their K columns in channel order
-        blocks = [tuple(b[:2]) + (_wh_natural_k(b[2]),) + tuple(b[3:]) for b in blocks]
     ptrs = []
     for blk in blocks:
         assert len(blk) == 13
@@ -359,49 +355,26 @@ def fused_blocks32(x, table):
     return x
 
 
-_WH_NATURAL = {}
-
-
-def _wh_natural_k(wh):
-    """The one-wave-per-window kernel (fused_block64.hip) reads LayerNorm1 in natural channel order: undo the K-column order
-    packing.pack_qkv_heads gives the default kernels."""
-    from . import packing
-    dev = wh.device
-    if str(dev) not in _WH_NATURAL:
-        _WH_NATURAL[str(dev)] = torch.argsort(packing._fused_k_order(dev))
-    return wh.index_select(2, _WH_NATURAL[str(dev)]).contiguous()
-
-
-def fused_blocks64(x, table):
-    """In place: the table's consecutive WindowTransformerBlocks in one launch, one wave per window (inference)."""
+def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2):
+    """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion).
+    w1 / b1 = mlp.0 scaled by 1/4 (packing.pack_fc1_fused_q), w2 = 4 mlp.2.weight in fp16 (packing.pack_fc2_h4)."""
     M = x.shape[0]
     assert M % 64 == 0
-    arr, nblk, _keep = table
-    _lib.call("tup_fused_blocks64_fwd", _chk(x, F32, (M, 192), "x"), arr, nblk, M // 64, _stream())
-    return x
-
-
-def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2, tokens_per_wave=None):
-    """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion)."""
-    M = x.shape[0]
-    assert M % 64 == 0
-    tpw = block_tokens_per_wave if tokens_per_wave is None else tokens_per_wave
-    if tpw == 64:
-        return fused_blocks64(x, block_table([(gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2)], natural_k=True))
     _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
               _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
               _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"),
               _chk(gamma2, F32, (192,), "gamma2"), _chk(beta2, F32, (192,), "beta2"),
-              _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, BF16, (192, 768), "w2"), _chk(b2, F32, (192,), "b2"),
+              _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, F16, (192, 768), "w2"), _chk(b2, F32, (192,), "b2"),
               M // 64, _stream())
     return x
 
 
 def fused_mlp(x, gamma, beta, w1, b1, w2, b2):
-    """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip)."""
+    """In place: x += mlp.2(GELU(mlp.0(LayerNorm(x)))) (inference fusion; hidden tensor stays on chip).
+    w1 / b1 = mlp.0 scaled by 1/4 (packing.pack_fc1_fused_q), w2 = 4 mlp.2.weight in fp16 (packing.pack_fc2_h4)."""
     M = x.shape[0]
     _lib.call("tup_fused_mlp_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma, F32, (192,), "gamma"), _chk(beta, F32, (192,), "beta"),
-              _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, BF16, (192, 768), "w2"),
+              _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, F16, (192, 768), "w2"),
               _chk(b2, F32, (192,), "b2"), M, _stream())
     return x
 

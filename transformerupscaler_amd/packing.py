@@ -113,6 +113,19 @@ def pack_fc1_fused(weight: torch.Tensor):
     return pack_linear(weight).index_select(1, _fused_k_order(weight.device)).contiguous()
 
 
+def pack_fc1_fused_q(weight: torch.Tensor, bias: torch.Tensor):
+    """mlp.0 for the fused inference MLPs (tup_fused_mlp_fwd, tup_fused_block_fwd, tup_fused_blocks32_fwd): pack_fc1_fused of
+    W1 / 4 and b1 / 4.  A power of two, so exact in bf16 / fp32: FC1's accumulators then hold x / 4, the range in which the GELU
+    polynomial is evaluated in packed fp16 (csrc/common.h, gelu16_batch)."""
+    return pack_fc1_fused(weight.detach() * 0.25), (bias.detach().float() * 0.25).contiguous()
+
+
+def pack_fc2_h4(weight: torch.Tensor):
+    """mlp.2 for the same kernels: 4 W2 in FP16 (rows permuted per 64-group as pack_linear): the hidden tile gelu(x) / 4 stays fp16
+    and FC2 runs on v_mfma_f32_16x16x32_f16; fp16 carries three more mantissa bits than the bf16 tile it replaces."""
+    return perm_rows64(weight.detach() * 4.0).contiguous().to(torch.float16)
+
+
 def _fused_k_order(device):
     """Column order of the weights that follow a LayerNorm inside the fused block kernels: K-step st, lane group g, element j
     contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j (the channels whose residual the same lane carries in its accumulators)."""
@@ -279,7 +292,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
         for i in range(BLOCKS):
             pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"window_blocks.{i}.attn.qkv.weight"], sd[f"window_blocks.{i}.attn.qkv.bias"])
             pk[f"b{i}.proj.wpp"] = pack_proj_pairs(sd[f"window_blocks.{i}.attn.proj.weight"])
-            pk[f"b{i}.fc1.wf"] = pack_fc1_fused(sd[f"window_blocks.{i}.mlp.0.weight"].detach())
+            pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"] = pack_fc1_fused_q(sd[f"window_blocks.{i}.mlp.0.weight"], sd[f"window_blocks.{i}.mlp.0.bias"])
+            pk[f"b{i}.fc2.wh4"] = pack_fc2_h4(sd[f"window_blocks.{i}.mlp.2.weight"])
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
     pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])

@@ -122,20 +122,38 @@ def rt_cpu_baseline():
             "sample": f"{n} forward+backward passes of 1 image 720x1280 -> 4320x7680 fp32 (L1 loss, dropout off) after 1 warm-up"}
 
 
-def pmc_traffic(kernel_key: str):
+def pmc_traffic(kernel_key: str, mode: str = "infer"):
     """HBM bytes per launch from the committed PMC run of this round, or None when the kernel's source changed since
     (the JSON records the sha256 of the .hip file it was measured on; a stale number is worse than none)."""
+    name = f"r03_pmc_traffic_{mode}.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             pm = json.load(f)
         ent = pm[kernel_key]
         with open(os.path.join(ROOT, "transformerupscaler_amd", "csrc", ent["source"]), "rb") as f:
             sha = hashlib.sha256(f.read()).hexdigest()
         if sha != ent["source_sha256"]:
-            return None, f"stale: {ent['source']} changed since profiles/r02_pmc_traffic.json was measured"
-        return ent["traffic_bytes_per_launch"], "profiles/r02_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
+            return None, f"stale: {ent['source']} changed since profiles/{name} was measured"
+        return ent["traffic_bytes_per_launch"], f"profiles/{name} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)"
     except Exception as e:          # noqa: BLE001
         return None, f"unavailable ({type(e).__name__})"
+
+
+def pmc_mfma(kernel_key: str):
+    """Counter-based matrix-pipe utilisation of the committed PMC run (profiles/r03_pmc_mfma.json): SQ_VALU_MFMA_BUSY_CYCLES over
+    every SIMD-cycle of the launch (rocprof's MfmaUtil expression) and the clock the chip held, or None when stale / absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")) as f:
+            ent = json.load(f)[kernel_key]
+        with open(os.path.join(ROOT, "transformerupscaler_amd", "csrc", ent["source"]), "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest() != ent["source_sha256"]:
+                return None
+        d = ent["derived"]
+        return {"mfma_util": d.get("mfma_util"), "clock_GHz": d.get("clock_GHz_from_GRBM_GUI_ACTIVE"),
+                "wait_any_share": d.get("sq_wait_any_share_of_wave_cycles"), "issue_stall_share": d.get("sq_wait_inst_any_share_of_wave_cycles"),
+                "source": "profiles/r03_pmc_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ..., own pass)"}
+    except Exception:          # noqa: BLE001
+        return None
 
 
 def launcher_decision(gpus: int, environ) -> str:
@@ -338,6 +356,18 @@ def main():
             step()
         torch.cuda.synchronize()
         barrier()
+        # event timing of the attention launches (the dominant kernels of this step) on the launch stream
+        from transformerupscaler_amd import autograd_rt
+        attn_ev = {"rt_attn_fwd": [], "rt_attn_bwd": []}
+
+        @contextlib.contextmanager
+        def rt_timer(name):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record()
+            yield
+            e_.record()
+            attn_ev[name].append((s_, e_))
+
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -345,13 +375,34 @@ def main():
         torch.cuda.synchronize()
         barrier()
         dtt = time.perf_counter() - t0
+        autograd_rt.stage_timer = rt_timer          # three more steps, outside the timed region, with the events armed
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        autograd_rt.stage_timer = None
+        fwd_ms = sum(a.elapsed_time(b) for a, b in attn_ev["rt_attn_fwd"]) / max(len(attn_ev["rt_attn_fwd"]), 1)
+        bwd_ms = sum(a.elapsed_time(b) for a, b in attn_ev["rt_attn_bwd"]) / max(len(attn_ev["rt_attn_bwd"]), 1)
+        # algorithmic FLOPs of the attention GEMMs per TransformerBlock (models/ResidualTransformer/model.py:40-50, hd = 16, 8 heads,
+        # N = 3600): forward QK^T + PV = 2 products, backward dq pass recomputes S and forms dP, dQ (3), dkv pass recomputes S
+        # and forms dP, dV, dK (4) -> 9 products of 2 * N^2 * 16 FLOP per head and image
+        unit = 2.0 * 3600 * 3600 * 16 * 8 * args.rt_batch
+        trio_ms = fwd_ms + bwd_ms
+        rt_roof = {"bound": "valu",
+                   "kernel": "rt_attention_kernel + rt_attn_bwd_dq_kernel + rt_attn_bwd_dkv_kernel (flash-style attention of one TransformerBlock, "
+                             "forward and backward, N = 3600 tokens, 8 heads x 16)",
+                   "achieved": 9 * unit / (trio_ms * 1e-3) / 1e12 if trio_ms > 0 else 0.0, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": (9 * unit / (trio_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS) if trio_ms > 0 else 0.0,
+                   "ms_fwd_per_block": fwd_ms, "ms_bwd_per_block": bwd_ms, "blocks_per_step": 8, "launch_groups_timed": len(attn_ev["rt_attn_fwd"]),
+                   "algorithmic_flop_per_block": 9 * unit, "traffic": None,
+                   "note": "K = 16 products: 64 MFMA FLOP per score against an exp, the softmax arithmetic and a dropout hash per score on the VALU "
+                           "-- the trio is VALU-issue-bound, not MFMA-bound; frac is against the dense bf16 MFMA peak for comparability"}
         if dist is not None:
             t = torch.tensor([dtt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtt = float(t.item())
         rccl = rccl_info(dp)
         del dp
-        return {"rccl": rccl, "metric": "images/sec, ResidualTransformer 6x 720p->4320x7680 training step", "value": world * args.rt_batch * steps / dtt,
+        return {"roofline": rt_roof, "rccl": rccl, "metric": "images/sec, ResidualTransformer 6x 720p->4320x7680 training step", "value": world * args.rt_batch * steps / dtt,
                 "unit": "images/sec", "ms_per_step": dtt / steps * 1e3, "steps": steps, "images_per_gpu_per_step": args.rt_batch,
                 "global_batch": world * args.rt_batch, "loss": float(loss.item()), "dropout": "p=0.1 (train mode, stateless hash masks)",
                 "parallelism": f"dp{world}" + (" RCCL all-reduce of 12.8 MB fp32 grads, overlapped with backward" if world > 1 else ""),
@@ -479,7 +530,7 @@ def main():
                                                                        else "one block per launch, 6 launches per forward)"),
                   "blocks_per_launch": 6 // n_block_launch, "ms_per_block": blocks_ms / 6,
                   "achieved": attn_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / MFMA_BF16_PEAK_TFLOPS,
-                  "traffic": blk_traffic, "traffic_source": blk_src,
+                  "traffic": blk_traffic, "traffic_source": blk_src, "counters": pmc_mfma("fused_block"),
                   "algorithmic_flop_per_launch": ATTN_SET_FLOP_PER_IMAGE * args.batch / n_block_launch,
                   # SURVEY 8(d)'s per-block figure (the fp32 residual stream read once + written once) x the blocks one launch runs
                   "algorithmic_bytes": nwin * 64 * 192 * 4 * 2 * (6 // n_block_launch),
@@ -488,7 +539,7 @@ def main():
                           "LayerNorm / softmax / GELU run inside the same launches and are not counted; north_star target frac >= 0.40"}
     roof_conv = {"bound": "mfma", "kernel": "conv_c64_persistent_kernel<4,0,3> (conv2 64->64 3x3 implicit GEMM; same kernel as decoder_conv1; 2 launches per forward)",
                  "achieved": conv_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / MFMA_BF16_PEAK_TFLOPS,
-                 "traffic": conv_traffic, "traffic_source": conv_src,
+                 "traffic": conv_traffic, "traffic_source": conv_src, "counters": pmc_mfma("conv64"),
                  "algorithmic_flop_per_launch": CONV64_FLOP_PER_IMAGE * args.batch,
                  "algorithmic_bytes": 2 * args.batch * LR_H * LR_W * 64 * 2,
                  "ms_per_launch": conv_ms, "total_ms_per_forward": 2 * conv_ms, "launches_timed": len(events)}

@@ -4,21 +4,46 @@
 (FETCH_SIZE x 2 on gfx950 for wide coalesced reads + WRITE_SIZE, both reported in KB) and the rate at the traced duration.
 Each entry records the sha256 of the kernel's source file; bench.py reports `traffic` only while that still matches.
 
-    python scripts/pmc_traffic.py <fetch_dir> <write_dir> <stats_csv> <out_json>
+    python scripts/pmc_traffic.py <fetch_dir> <write_dir> <stats_csv> <out_json> [infer|x4|train|rt]
 """
 import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEYS = {  # bench.py key -> (substring of the kernel name, source file, algorithmic bytes per launch at B = 8 or None)
-    "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 1920 * 64 * 192 * 4 * 2),   # six blocks per launch
-    "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 8 * 720 * 1280 * 64 * 2),
-    "tail": ("tail_fused_kernel", "tail_fused.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
-    "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", None),
-    "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip", None),
-    "branch_a_5x5": ("conv_c64_persistent_kernel<1, 1, 5>", "conv3x3_c64.hip", None),
-    "conv1": ("conv3x3_c3_persistent_kernel", "conv_thin.hip", None),
-    "decoder_conv2": ("conv_c64_persistent_kernel<1, 1, 3>", "conv3x3_c64.hip", None),
+MB = 1e6
+# bench.py key -> (substring of the kernel name, source file, algorithmic bytes per launch = every operand read once + every result
+# written once at the mode's batch).  720p = 720 x 1280 LR, NHWC bf16 64-channel maps = 118 MB per image.
+F64 = 720 * 1280 * 64 * 2            # one 64-channel bf16 map of a 720p image
+KEYS = {
+    "infer": {   # B = 8, 2x 720p -> 1080p
+        "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 1920 * 64 * 192 * 4 * 2),      # six blocks per launch
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 8 * F64),
+        "tail": ("tail_stream_r2_kernel<true>", "tail_stream.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
+        "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", 1920 * 64 * 192 * 4 + 2 * 8 * F64),
+        "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip", 8 * F64 + 1920 * 64 * 192 * 4),
+        "branch_a_5x5": ("conv_c64_persistent_kernel<1, 1, 5>", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 1440 * 2560 * 4),
+        "conv1": ("conv3x3_c3_persistent_kernel", "conv_thin.hip", 8 * 3 * 720 * 1280 * 4 + 8 * F64),
+        "decoder_conv2": ("conv_c64_persistent_kernel<1, 1, 3>", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 720 * 1280 * 4),
+    },
+    "x4": {      # B = 4, 4x 540p -> 2160p: the tail's last stage runs 1080p -> 2160p without a Resize
+        "tail": ("tail_stream_r2_kernel<false>", "tail_stream.hip", 4 * 3 * (1080 * 1920 + 2 * 2160 * 3840) * 4),
+        "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 540 * 64 * 192 * 4 * 2),        # 4 x 135 windows
+        "branch_a_5x5": ("conv_c64_persistent_kernel<1, 1, 5>", "conv3x3_c64.hip", 4 * 1080 * 1920 * 64 * 2 + 4 * 3 * 2160 * 3840 * 4),
+    },
+    "train": {   # B = 4, 2x 720p -> 1080p training step
+        "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 192 * 2 + 576 * 2)),      # qkv + d att in, d qkv out
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 4 * F64),
+        "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip", 2 * 4 * F64),
+        "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),
+    },
+    "rt": {      # B = 2, ResidualTransformer 6x training step
+        "rt_attn_fwd": ("rt_attention_kernel<true>", "rt_kernels.hip", 2 * 3600 * (384 + 128) * 2 + 2 * 8 * 3600 * 4),
+        "rt_attn_bwd_dq": ("rt_attn_bwd_dq_kernel<true>", "rt_kernels.hip", 2 * 3600 * (384 + 128 + 128) * 2),
+        "rt_attn_bwd_dkv": ("rt_attn_bwd_dkv_kernel<true>", "rt_kernels.hip", 2 * 3600 * (384 + 128 + 256) * 2),
+        "bicubic_bwd_rows": ("rt_bicubic_bwd_rows_band_kernel", "rt_kernels.hip", 2 * 3 * 4320 * 7680 * 4 * 2),
+        "bicubic_sum": ("rt_bicubic_sum_sep_kernel", "rt_kernels.hip", 2 * 3 * 4320 * 7680 * 4),
+        "l1_partial": ("l1_partial_kernel", "loss.hip", 2 * 2 * 3 * 4320 * 7680 * 4),
+    },
 }
 
 
@@ -33,12 +58,13 @@ def counter_means(d, counter):
 
 def main():
     fetch_dir, write_dir, stats_csv, out = sys.argv[1:5]
+    mode = sys.argv[5] if len(sys.argv) > 5 else "infer"
     fetch, write = counter_means(fetch_dir, "FETCH_SIZE"), counter_means(write_dir, "WRITE_SIZE")
     dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(stats_csv))}
-    res = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --mode infer "
+    res = {"_note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `bench.py --steps 3 --warmup 1 --mode {mode} "
                     "--no-cpu-baseline`; counters are in KB; reads x 2 (gfx950 tallies a 128-B request as 64 B), writes exact; "
                     "durations from the --kernel-trace --stats pass"}
-    for key, (sub, src, alg) in KEYS.items():
+    for key, (sub, src, alg) in KEYS[mode].items():
         names = [n for n in fetch if sub in n]
         if not names:
             continue

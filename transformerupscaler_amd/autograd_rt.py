@@ -13,6 +13,22 @@ import torch
 from . import ops, packing
 from .autograd import site_seed
 
+# Optional timing hook (bench.py --mode rt installs one): callable(name) -> context manager around the attention launches
+# ("rt_attn_fwd" = rt_attention_kernel, "rt_attn_bwd" = the dq + dkv pair).
+stage_timer = None
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _stage(name):
+    return stage_timer(name) if stage_timer is not None else _Null()
+
 
 def forward_train(pk, x, res_out, drop_p: float, seed: int):
     B, _, H, W = x.shape
@@ -29,7 +45,8 @@ def forward_train(pk, x, res_out, drop_p: float, seed: int):
         s = {"x_in": xw}
         y1, s["mean1"], s["rstd1"] = ops.layernorm128(xw, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], save_stats=True)
         qkv = ops.gemm_tokens(y1, pk[f"b{i}.in.w"], pk[f"b{i}.in.b"], "bf16")
-        att, lse = ops.rt_attention(qkv, B, N, save_lse=True, drop_p=drop_p, drop_seed=site_seed(seed, i, 0))
+        with _stage("rt_attn_fwd"):
+            att, lse = ops.rt_attention(qkv, B, N, save_lse=True, drop_p=drop_p, drop_seed=site_seed(seed, i, 0))
         x_mid = ops.gemm_tokens(att, pk[f"b{i}.out.w"], pk[f"b{i}.out.b"], "res", res=xw)
         y2, s["mean2"], s["rstd2"] = ops.layernorm128(x_mid, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], save_stats=True)
         hpre = torch.empty((y2.shape[0], 512), dtype=torch.bfloat16, device=x.device)
@@ -92,7 +109,8 @@ def backward_train(pk, sv, gout, reducer=None, l1_scale=None) -> Dict[str, torch
             g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
         g[p + ".attn.out_proj.weight"], g[p + ".attn.out_proj.bias"] = ops.gemm_wgrad_bias(g_xm, s["att"])
         g_att = ops.gemm_tokens(g_xm, pk[f"b{i}.out.wd"], None, "bf16")
-        g_qkv = ops.rt_attention_bwd(s["qkv"], s["att"], g_att, s["lse"], B, N, drop_p=drop_p, drop_seed=site_seed(seed, i, 0))
+        with _stage("rt_attn_bwd"):
+            g_qkv = ops.rt_attention_bwd(s["qkv"], s["att"], g_att, s["lse"], B, N, drop_p=drop_p, drop_seed=site_seed(seed, i, 0))
         g[p + ".attn.in_proj_weight"], g[p + ".attn.in_proj_bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.in.wd"], None, "bf16")
         del g_qkv, g_att

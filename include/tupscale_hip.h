@@ -356,11 +356,11 @@ int tup_fused_attn_block_fwd(float* x, const float* gamma, const float* beta, co
 
 /* One whole WindowTransformerBlock in place (model.py:153-172): x += proj(attention(qkv(norm1(x)))) followed by
  * x += mlp.2(GELU(mlp.0(norm2(x)))) in ONE kernel: the residual stream of a 128-token tile stays in registers between
- * the two halves.  Arguments: those of tup_fused_attn_block_fwd, then norm2 / mlp.0 / mlp.2 as in tup_fused_mlp_fwd. */
-int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const void* wh, const float* bh,
-                        const float* bias_frag, const void* wproj, const float* bproj,
-                        const float* gamma2, const float* beta2, const void* w1, const float* b1,
-                        const void* w2, const float* b2, int nwin, void* stream);
+ * the two halves.  norm1 / norm2's scale and shift arrive folded into attn.qkv / mlp.0 (packing.fold_layernorm: W diag(gamma),
+ * b + W beta): wh / bh = pack_qkv_heads of the folded qkv, w1 / b1 = pack_fc1_fused_q of the folded mlp.0 (x 1/4), w2 = 4 mlp.2.weight
+ * in fp16 (pack_fc2_h4); bias_frag, wproj, bproj as in tup_fused_attn_block_fwd. */
+int tup_fused_block_fwd(float* x, const void* wh, const float* bh, const float* bias_frag, const void* wproj, const float* bproj,
+                        const void* w1, const float* b1, const void* w2, const float* b2, int nwin, void* stream);
 
 /* Branch A in TRAINING through its exact composition (r = 2): replaces autograd through `self.up1(feat)` + `self.up1_conv(...)`,
  * model.py:264-265 (Upsampler utils.py:62-63 + BasicConv utils.py:32-40; no non-linearity between the two convs, utils.py:50).
@@ -395,7 +395,7 @@ int tup_resize_u8_cols(const void* src, void* dst_u8, float* dst_f32, const int*
 /* nblk (<= 8) consecutive WindowTransformerBlocks in ONE launch (the loop `for block in self.window_blocks`, model.py:288-289), with
  * the default kernel's geometry (two waves per window, two workgroups per CU): between blocks the residual stream passes through
  * memory as each wave's own stores followed by its own loads (L2), so the launch boundaries and their chip-wide load / store bursts
- * disappear.  x fp32 [64*nwin][192] in place; table: HOST array [nblk][13] of device pointers, per block the arguments of
+ * disappear.  x fp32 [64*nwin][192] in place; table: HOST array [nblk][9] of device pointers, per block the arguments of
  * tup_fused_block_fwd after x in that order and packing. */
 int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
 

@@ -11,24 +11,27 @@ import test_hip_kernels as T
 nwin, rounds = 1920, 15
 libs = dict(a.split("=") for a in sys.argv[1:])
 raw, args = T._block_operands("cuda", nwin)
-args_bf16 = args
 x0 = raw["x"].to("cuda")
-arr, nblk, keep = ops.block_table([tuple(args)] * 6)
+# libraries built before ABI 9 (flag "@abi8") take gamma / beta explicitly: 13 pointers per block instead of 9
+from transformerupscaler_amd import packing
+_wh, _bh = packing.pack_qkv_heads(raw["w"], raw["b"])
+_w1, _b1 = packing.pack_fc1_fused_q(raw["w1"], raw["b1"])
+args8 = [raw["gm1"].cuda(), raw["bt1"].cuda(), _wh.cuda(), _bh.cuda(), args[2], args[3], args[4], raw["gm2"].cuda(), raw["bt2"].cuda(),
+         _w1.cuda(), _b1.cuda(), args[7], args[8]]
 P, I = ctypes.c_void_p, ctypes.c_int
 runs = {}
-wh_perm = args[2]
-keep = [keep]
+keep = []
 for name, path in libs.items():
     path, _, flag = path.partition("@")
     L = ctypes.CDLL(os.path.join(root, path))
-    L.tup_fused_block_fwd.argtypes = [P] * 14 + [I, P]
-    ptrs = [a.data_ptr() for a in args]
+    a = args8 if flag == "abi8" else args
+    L.tup_fused_block_fwd.argtypes = [P] * (1 + len(a)) + [I, P]
+    ptrs = [t.data_ptr() for t in a]
     runs[name + "/6 launches"] = (lambda x, L=L, ptrs=ptrs: [L.tup_fused_block_fwd(x.data_ptr(), *ptrs, nwin, None) for _ in range(6)])
-    if hasattr(L, "tup_fused_blocks32_fwd"):
-        L.tup_fused_blocks32_fwd.argtypes = [P, P, I, I, P]
-        tab = ops.block_table([tuple(args)] * 6)
-        keep.append(tab)
-        runs[name + "/1 launch"] = (lambda x, L=L, tab=tab: L.tup_fused_blocks32_fwd(x.data_ptr(), tab[0], 6, nwin, None))
+    L.tup_fused_blocks32_fwd.argtypes = [P, P, I, I, P]
+    tab = (ctypes.c_void_p * (6 * len(a)))(*(ptrs * 6))
+    keep.append(tab)
+    runs[name + "/1 launch"] = (lambda x, L=L, tab=tab: L.tup_fused_blocks32_fwd(x.data_ptr(), tab, 6, nwin, None))
 x = x0.clone()
 ref = None
 for k, f in runs.items():

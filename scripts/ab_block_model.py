@@ -28,9 +28,8 @@ m = importlib.import_module("models.FastTransformer.model").TransformerModel()
 m.load_state_dict(deterministic_state_dict(0), strict=False)
 m = m.to(dev).eval()
 pk, frags = m.packed(2)
-mt = ops.block_table([(pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], frags[i], pk[f"b{i}.proj.wpp"],
-                       pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"],
-                       pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)])
+from transformerupscaler_amd.engine import _block_operands
+mt = ops.block_table([_block_operands(pk, i, frags) for i in range(BLOCKS)])
 tabs["model-w"] = (x_rand, mt)
 g = torch.Generator().manual_seed(1234)
 img = torch.rand((8, 3, 720, 1280), generator=g).to(dev)

@@ -1,0 +1,18 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r3l; rm -rf $O; mkdir -p $O
+B=transformerupscaler_amd/csrc/build
+timeout -k 10 300 python3 scripts/ab_block.py bufdma=$B/ab_bufdma.so@abi8 new=transformerupscaler_amd/libtupscale_hip.so > $O/ab.log 2>&1; tail -9 $O/ab.log
+timeout -k 10 900 python3 -m pytest tests -m gpu -q -s > $O/tests.log 2>&1 || (grep -n "^FAILED\|^E " $O/tests.log | head -30; echo TESTS FAILED)
+tail -2 $O/tests.log
+grep -n "whole block (folded\|nwin .*vs torch" $O/tests.log | head
+timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
+python3 - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r3l/bench.json').read().strip().splitlines()[-1])
+print('infer', d['value'], d['ms_per_step']); r=d['roofline']; print('roof', r['frac'], r['ms_per_launch'], r['kernel'][:30])
+print('train', d['train']['value'], d['train']['ms_per_step']); print('rt', d['rt_train']['value'], d['rt_train']['ms_per_step']); print('x4', d['x4']['value'], d['x4']['ms_per_step'])
+print('fid', d['fidelity']['psnr_vs_ref_db'], d['fidelity']['max_abs_vs_ref'], d['fidelity']['delta_psnr_vs_hr_db'])
+PY
+echo all done

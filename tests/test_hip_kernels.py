@@ -593,8 +593,8 @@ def test_fused_attention_block(dev, nwin):
 @pytest.mark.parametrize("nwin", [1, 2, 5, 64])
 def test_fused_block_equals_two_halves(dev, nwin):
     """tup_fused_block_fwd (whole WindowTransformerBlock, model.py:153-172, one kernel) against the attention-half kernel
-    followed by the MLP-half kernel: the same arithmetic on the same registers, so the results are identical; and both
-    against torch through the checks of the two halves above."""
+    followed by the MLP-half kernel (which apply gamma / beta themselves): the same block to bf16 noise; and both against torch
+    through the checks of the two halves above and test_block_vs_torch."""
     from transformerupscaler_amd import ops, packing
     g = torch.Generator().manual_seed(23)
     M = nwin * 64
@@ -610,13 +610,20 @@ def test_fused_block_equals_two_halves(dev, nwin):
     wh, bh = wh.to(dev), bh.to(dev)
     frag = ops.relpos_bias_expand(table.to(dev))
     wpp = packing.pack_proj_pairs(wp).to(dev)
-    w1f, b1 = packing.pack_fc1_fused_q(w1, b1.cpu())
+    b1_raw = b1.cpu()
+    w1f, b1 = packing.pack_fc1_fused_q(w1, b1_raw)
     w1f, b1, w2p = w1f.to(dev), b1.to(dev), packing.pack_fc2_h4(w2).to(dev)
     two = ops.fused_attn_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp)
     two = ops.fused_mlp(two, gm2, bt2, w1f, b1, w2p, b2)
-    one = ops.fused_block(x.clone(), gm1, bt1, wh, bh, frag, wpp, bp, gm2, bt2, w1f, b1, w2p, b2)
+    # the whole-block kernel takes the LayerNorms folded into the Linears (same function of x; the bf16 roundings fall on
+    # xhat and W gamma instead of on LN(x) and W): agreement to the bf16 noise of one block, not bit for bit
+    whn, bhn = packing.pack_qkv_heads(*packing.fold_layernorm(w, b, gm1.cpu(), bt1.cpu()))
+    w1n, b1n = packing.pack_fc1_fused_q(*packing.fold_layernorm(w1, b1_raw, gm2.cpu(), bt2.cpu()))
+    one = ops.fused_block(x.clone(), whn.to(dev), bhn.to(dev), frag, wpp, bp, w1n.to(dev), b1n.to(dev), w2p, b2)
     assert torch.isfinite(one).all()
-    assert (one - two).abs().max().item() <= 1e-5, (one - two).abs().max().item()
+    d = (one - two).abs()
+    print(f"whole block (folded LayerNorms) vs two halves: max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    assert d.max().item() <= 4e-2 and d.mean().item() <= 6e-3, (d.max().item(), d.mean().item())      # seen: 2.5e-2, 3.5e-3
     assert (one - x).abs().max().item() > 0.1            # the block did something
 
 
@@ -632,10 +639,12 @@ def _block_operands(dev, nwin, seed=23):
                w1=torch.randn((768, 192), generator=g) * 0.08, b1=0.2 * torch.randn(768, generator=g),
                w2=torch.randn((192, 768), generator=g) * 0.05, b2=0.2 * torch.randn(192, generator=g),
                table=0.5 * torch.randn((225, 12), generator=g))
-    wh, bh = packing.pack_qkv_heads(raw["w"], raw["b"])
-    args = [raw["gm1"].to(dev), raw["bt1"].to(dev), wh.to(dev), bh.to(dev), ops.relpos_bias_expand(raw["table"].to(dev)),
-            packing.pack_proj_pairs(raw["wp"]).to(dev), raw["bp"].to(dev), raw["gm2"].to(dev), raw["bt2"].to(dev),
-            *[t.to(dev) for t in packing.pack_fc1_fused_q(raw["w1"], raw["b1"])], packing.pack_fc2_h4(raw["w2"]).to(dev), raw["b2"].to(dev)]
+    # the whole-block kernels take norm1 / norm2 folded into attn.qkv / mlp.0 (packing.fold_layernorm)
+    wh, bh = packing.pack_qkv_heads(*packing.fold_layernorm(raw["w"], raw["b"], raw["gm1"], raw["bt1"]))
+    args = [wh.to(dev), bh.to(dev), ops.relpos_bias_expand(raw["table"].to(dev)),
+            packing.pack_proj_pairs(raw["wp"]).to(dev), raw["bp"].to(dev),
+            *[t.to(dev) for t in packing.pack_fc1_fused_q(*packing.fold_layernorm(raw["w1"], raw["b1"], raw["gm2"], raw["bt2"]))],
+            packing.pack_fc2_h4(raw["w2"]).to(dev), raw["b2"].to(dev)]
     return raw, args
 
 

@@ -117,11 +117,11 @@ def test_fused_adam_host_runs_ahead_without_corrupting_steps(det_sd):
         res[tag] = ([float(v) for v in losses], [p.detach().clone() for p in m.parameters()])
     la, pa = res["async"]
     ls, ps = res["sync"]
-    # the same trajectory: the first steps to rounding, the later ones to the divergence that the weight-gradient kernels' fp32
-    # atomics (order-dependent last bits) seed and Adam's +-lr steps amplify -- a step run with another step's lr / bc1 or
-    # gradient pointers would be off by percent
+    # the same trajectory: the first step to rounding (same weights), the later ones to the divergence that the weight-gradient
+    # kernels' fp32 atomics (order-dependent last bits) seed and Adam's first, sign-like +-lr steps amplify (1.5e-4 seen at the
+    # third loss) -- a step run with another step's lr / bc1 or gradient pointers would be off by percent
     for i, (a, b) in enumerate(zip(la, ls)):
-        assert abs(a - b) <= (1e-5 if i < 3 else 2e-3) * abs(b), (i, la, ls)
+        assert abs(a - b) <= (1e-5 if i < 1 else 2e-3) * abs(b), (i, la, ls)
     tot = bad = 0
     for a, b in zip(pa, ps):
         d = (a - b).abs()

@@ -45,12 +45,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         const bool ok = row < M;
         const int r = ok ? row : 0;
         const float mu = mean[r], rs = rstd[r];
-        float xh[NQ * 4], gg[NQ * 4], s1 = 0.f, s2 = 0.f;
+        // every load of the row stands ahead of the arithmetic (x, gy and the residual-path gradient that is only added at the
+        // end): the kernel is a 165 MB stream per launch, its speed is the number of loads a wave keeps in flight
+        f32x4 xq[NQ], rq[NQ];
+        u32x2 gq[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int c = q * 64 + sub * 4;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)r * LD + c);
-            const u32x2 gv = *reinterpret_cast<const u32x2*>(gy + (size_t)r * LD + c);
+            xq[q] = *reinterpret_cast<const f32x4*>(x + (size_t)r * LD + c);
+            gq[q] = *reinterpret_cast<const u32x2*>(gy + (size_t)r * LD + c);
+            rq[q] = gres ? *reinterpret_cast<const f32x4*>(gres + (size_t)r * LD + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float xh[NQ * 4], gg[NQ * 4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const f32x4 xv = xq[q];
+            const u32x2 gv = gq[q];
             const float gyv[4] = {__builtin_bit_cast(float, gv[0] << 16), __builtin_bit_cast(float, gv[0] & 0xffff0000u),
                                   __builtin_bit_cast(float, gv[1] << 16), __builtin_bit_cast(float, gv[1] & 0xffff0000u)};
 #pragma unroll
@@ -73,11 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (gg[q * 4 + e] - s1 - xh[q * 4 + e] * s2);
-                if (gres) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(gres + (size_t)row * LD + c);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += rv[e];
-                }
+                for (int e = 0; e < 4; ++e) o[e] += rq[q][e];
                 *reinterpret_cast<f32x4*>(dx + (size_t)row * LD + c) = o;
             }
         }
@@ -360,14 +367,24 @@ extern "C" int tup_dropout_bwd(const float* gin, void* gout, long long n, float 
     return 0;
 }
 
+namespace {
+// 16 rows per block and sweep; the grid is the number of row groups divided by the smallest sweep count that fits 1,280 blocks
+// (five per CU), so every block runs the same number of sweeps (61,440 rows: 1,280 blocks x 3 instead of 1,024 x 3.75)
+int ln_bwd_blocks(int M)
+{
+    const int groups = (M + 15) / 16;
+    const int sweeps = (groups + 1279) / 1280;
+    return (groups + sweeps - 1) / sweeps;
+}
+}  // namespace
+
 // dx = LN'(gy) [+ gres]; dgamma/dbeta (fp32 [192]) are accumulated (caller zeroes them).
 extern "C" int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
                                  const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
                                  int M, void* stream)
 {
     if (M <= 0) return 0;
-    int blocks = (M + 15) / 16;
-    if (blocks > 1024) blocks = 1024;
+    const int blocks = ln_bwd_blocks(M);
     layernorm_bwd_kernel<3><<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
     TUP_CHECK_LAUNCH();
@@ -380,8 +397,7 @@ extern "C" int tup_layernorm128_bwd(const void* gy, const float* x, const float*
                                     int M, void* stream)
 {
     if (M <= 0) return 0;
-    int blocks = (M + 15) / 16;
-    if (blocks > 1024) blocks = 1024;
+    const int blocks = ln_bwd_blocks(M);
     layernorm_bwd_kernel<2><<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
     TUP_CHECK_LAUNCH();

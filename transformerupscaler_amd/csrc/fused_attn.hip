@@ -18,9 +18,6 @@
 #include <string.h>
 #include <stdlib.h>
 
-#ifndef TUP_FA_FRAG
-#define TUP_FA_FRAG 0
-#endif
 
 namespace {
 
@@ -46,6 +43,16 @@ TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
     return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
 }
 __device__ __attribute__((aligned(16))) unsigned int tup_fa_sink[64 * 2];       // store sink of inactive lanes (fixed vmcnt)
+// LDS-DMA of one 1 KB piece as a BUFFER load: resource descriptor (SGPRs) + per-lane byte offset (ONE VGPR, the same for every piece
+// of a stream) + wave-uniform byte offset of the piece (SGPR).  The global_load_lds form took a per-lane 64-bit pointer per piece:
+// one v_lshl_add_u64 each and a write-after-read dependence on that pointer register between consecutive pieces (234 pieces per
+// wave and block, ~100 cycles each in the stamps of DESIGN 5b); this form issues no VALU instruction at all.
+TUP_DEVICE void dma_piece(__amdgpu_buffer_rsrc_t r, char* lds_dst, uint32_t voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, soff, 0, 0);
+}
+TUP_DEVICE __amdgpu_buffer_rsrc_t weight_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
 
 // PROJ = true additionally runs attn.proj + the residual add (model.py:131,164) on the attention output while it is still
 // in registers: the 12 per-head O^T tiles ARE the token fragments of that GEMM (two heads = one K-step of 32, weight
@@ -88,6 +95,36 @@ TUP_DEVICE unsigned long long stamp_now32() {
 }
 enum { P_LN1 = 0, P_SYNC0, P_QKV, P_HBAR, P_ATT, P_PROJ, P_LN2, P_MTOP, P_FC1, P_W2BAR, P_GELU, P_FC2, P_STORE, P_TOTAL };
 
+// LayerNorm without scale / shift of one token group, from the accumulator layout (lane (g, pl): token pl, channels
+// (n >> 2) * 64 + 16 g + (n & 3) * 4 .. +3) straight into the B fragments of the product that follows (K-step st = values
+// n = 2 st, 2 st + 1; the following weight's K columns are packed to match, packing._fused_k_order).
+TUP_DEVICE void ln_fragments(const f32x4 (&v)[12], bf16x8 (&tf)[6])
+{
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int n = 0; n < 12; n += 2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s0 += v[n][e]; q0 = __builtin_fmaf(v[n][e], v[n][e], q0);
+            s1 += v[n + 1][e]; q1 = __builtin_fmaf(v[n + 1][e], v[n + 1][e], q1);
+        }
+    const float sum = rows_sum(s0 + s1), sq = rows_sum(q0 + q1);
+    const float mean = sum * (1.0f / DIM);
+    const float rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, sq * (1.0f / DIM)), 0.f) + 1e-5f);
+    const float shift = -mean * rstd;
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 u = v[2 * st + hh];
+            pk[2 * hh] = pack_bf16x2(__builtin_fmaf(u[0], rstd, shift), __builtin_fmaf(u[1], rstd, shift));
+            pk[2 * hh + 1] = pack_bf16x2(__builtin_fmaf(u[2], rstd, shift), __builtin_fmaf(u[3], rstd, shift));
+        }
+        tf[st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
+    }
+}
+
 template <bool PROJ, bool MLP = false, bool STAMPS = false>
 __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const float* __restrict__ x_in, bf16_t* __restrict__ out, int nwin, float* __restrict__ xio, const BlockTable tbl, int nblk)
@@ -129,46 +166,73 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const bf16_t* __restrict__ wh = bp.wh; const float* __restrict__ bh = bp.bh; const float* __restrict__ bias_frag = bp.bias_frag;
     const bf16_t* __restrict__ wproj = bp.wproj; const float* __restrict__ bproj = bp.bproj;
     const MlpArgs ma = bp.ma;
-    if (blk) __syncthreads();          // everyone is done with the previous block's LDS (weight slots, W2 chunk, biases)
-
-    float* qb = reinterpret_cast<float*>(smem + QB_OFF);
-    {   // fixed trip counts (tid is opaque to the compiler here): all loads first, then the stores
-        static_assert(HEADS * 48 == 576 && HID / 4 <= 256, "staging below assumes 576 biases and <= 256 float4 of b1");
-        const float q0 = bh[tid], q1 = bh[256 + tid], q2 = bh[512 + (tid & 63)];
-        f32x4 b1v = {};
-        if constexpr (MLP) b1v = reinterpret_cast<const f32x4*>(ma.b1)[tid < HID / 4 ? tid : 0];
-        qb[tid] = q0; qb[256 + tid] = q1;
-        if (tid < 64) qb[512 + tid] = q2;
-        if constexpr (MLP) {       // mlp.0's bias: behind everything the attention half uses, staged before any DMA is in flight
-            if (tid < HID / 4) reinterpret_cast<f32x4*>(smem + M_B1_OFF)[tid] = b1v;
-            if (tid < DIM) {
-                const float c0 = bproj[tid], c1 = ma.gamma2[tid], c2 = ma.beta2[tid], c3 = ma.b2[tid];
-                float* vec = reinterpret_cast<float*>(smem + M_VEC_OFF);
-                vec[tid] = c0; vec[DIM + tid] = c1; vec[2 * DIM + tid] = c2; vec[3 * DIM + tid] = c3;
+    // Order of the block's prologue: (first block of a launch) the x loads, the longest latency; the barrier that frees the
+    // previous block's LDS; the weight DMA of heads 0 and 1; the loads of the small vectors; LayerNorm1 (registers only from the
+    // second block on) while all of that is in flight; then the vectors' LDS stores.  Written as load / store / load / store the
+    // prologue was three dependent round trips (stamps: 8-10 k cycles per block for 3 k cycles of arithmetic).
+    if constexpr (MLP) {
+        if (blk == 0) {
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + g * 16;
+#pragma unroll
+                for (int n = 0; n < 12; ++n) xcar[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + (n & 3) * 4);
             }
         }
     }
+    if (blk) __syncthreads();          // everyone is done with the previous block's LDS (weight slots, W2 chunk, biases)
 
     // head h's weight slot by DMA: slot s = u*256 + tid -> k-tile u >> 1, row (u & 1)*32 + (tid >> 3), logical chunk
     // (tid & 7) ^ ((tid >> 4) & 7) (swizzle on the source side)
-    const bf16_t* w_thr = wh + (size_t)(tid >> 3) * DIM + ((tid & 7) ^ ((tid >> 4) & 7)) * 8;
+    // per-lane byte offsets of the weight streams: row (tid >> 3) of a 32-row half tile, 16-byte chunk (tid & 7) ^ swizzle, in a
+    // matrix of DIM (qkv, proj, mlp.0) or HID (mlp.2) columns
+    const uint32_t voff_d = (uint32_t)(((tid >> 3) * DIM + ((tid & 7) ^ ((tid >> 4) & 7)) * 8) * 2);
+    const uint32_t voff_h = (uint32_t)(((tid >> 3) * HID + ((tid & 7) ^ ((tid >> 4) & 7)) * 8) * 2);
     auto dma_w = [&](int h, int buf) {
+        const __amdgpu_buffer_rsrc_t r = weight_rsrc(wh);
         char* dst = smem + buf * FW_BYTES + wave * 1024;
-        const bf16_t* src = w_thr + (size_t)h * 64 * DIM;
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+        for (int u = 0; u < 6; ++u) dma_piece(r, dst + u * 4096, voff_d, (h * 64 * DIM + (u & 1) * 32 * DIM + (u >> 1) * 64) * 2);
     };
     dma_w(0, 0);
     dma_w(1, 1);
 
+    // fixed trip counts (tid is opaque to the compiler here)
+    static_assert(HEADS * 48 == 576 && HID / 4 <= 256, "staging below assumes 576 biases and <= 256 float4 of b1");
+    float* qb = reinterpret_cast<float*>(smem + QB_OFF);
+    const float q0 = bh[tid], q1 = bh[256 + tid], q2 = bh[512 + (tid & 63)];
+    f32x4 b1v = {};
+    float c0 = 0.f, c3 = 0.f;
+    if constexpr (MLP) {
+        b1v = reinterpret_cast<const f32x4*>(ma.b1)[tid < HID / 4 ? tid : 0];
+        c0 = bproj[tid < DIM ? tid : 0]; c3 = ma.b2[tid < DIM ? tid : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- LayerNorm1 straight into B fragments.  K-step st of the qkv product contracts over channels
     // 64 (st >> 1) + 16 g + 8 (st & 1) .. +8 = the lane's residual values n = 2 st, 2 st + 1 ----
-    // the loads (the wave's x rows in the first block of a launch, gamma, beta) stand together in program order, ahead of the
-    // arithmetic: written per row as load-then-use, hipcc under register pressure emits one global round trip per pair of loads
     bf16x8 tf[2][6];
-    {
+    if constexpr (MLP) {
+        // Whole-block form: gamma1 / beta1 are folded into the qkv weight and bias (packing.fold_layernorm), so the B fragments are
+        // the plain normalised values: one FMA per value, statistics in ONE sweep (sum and sum of squares, var = E[x^2] - mean^2 in
+        // fp32: the stream's |mean| / std stays far below the 2^12 where that form loses the bf16 digits the fragments keep), the
+        // four lane groups of a token joined by permlane swaps.  288 VALU instructions per LayerNorm instead of 576 + 24 loads.
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) ln_fragments(xcar[tg], tf[tg]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    qb[tid] = q0; qb[256 + tid] = q1;
+    if (tid < 64) qb[512 + tid] = q2;
+    if constexpr (MLP) {       // mlp.0's bias, b_proj, b2 (LayerNorm2's scale and shift live in mlp.0's weight and bias)
+        if (tid < HID / 4) reinterpret_cast<f32x4*>(smem + M_B1_OFF)[tid] = b1v;
+        if (tid < DIM) {
+            float* vec = reinterpret_cast<float*>(smem + M_VEC_OFF);
+            vec[tid] = c0; vec[DIM + tid] = c3;
+        }
+    }
+    if constexpr (!MLP) {
+        // the loads (the wave's x rows, gamma, beta) stand together in program order, ahead of the arithmetic: written per row as
+        // load-then-use, hipcc under register pressure emits one global round trip per pair of loads
         f32x4 gm[12], bt[12];
         if (!MLP || blk == 0) {
 #pragma unroll
@@ -231,34 +295,28 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 
     // PROJ: the attention output of this wave's 32 tokens, all heads: of[tg][h] = O^T tile (channels 4g.., token pl) as bf16x4
     s16x4 of[2][PROJ ? HEADS : 1];
-    const bf16_t* wp_thr = PROJ ? wproj + (size_t)(tid >> 3) * DIM + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 : nullptr;
     auto dma_wp = [&](int chunk, int buf) {                      // rows 64*chunk .. +63 of the packed proj weight
+        const __amdgpu_buffer_rsrc_t r = weight_rsrc(wproj);
         char* dst = smem + buf * FW_BYTES + wave * 1024;
-        const bf16_t* src = wp_thr + (size_t)chunk * 64 * DIM;
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
-                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+        for (int u = 0; u < 6; ++u) dma_piece(r, dst + u * 4096, voff_d, (chunk * 64 * DIM + (u & 1) * 32 * DIM + (u >> 1) * 64) * 2);
     };
 
     // MLP weight stream (same slot geometry and thread map as the qkv / proj slots)
-    const bf16_t* w1_thr = MLP ? ma.w1 + (size_t)(tid >> 3) * DIM + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 : nullptr;
-    const bf16_t* w2_thr = MLP ? ma.w2 + (size_t)(tid >> 3) * HID + ((tid & 7) ^ ((tid >> 4) & 7)) * 8 : nullptr;
     auto dma_w1_piece = [&](int j, int buf, int u) {
-        char* dst = smem + buf * FW_BYTES + wave * 1024;
-        const bf16_t* src = w1_thr + (size_t)j * 64 * DIM;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u & 1) * 32 * DIM + (u >> 1) * 64),
-                                         (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+        dma_piece(weight_rsrc(ma.w1), smem + buf * FW_BYTES + wave * 1024 + u * 4096, voff_d, (j * 64 * DIM + (u & 1) * 32 * DIM + (u >> 1) * 64) * 2);
     };
     auto dma_w2 = [&](int j) {
+        const __amdgpu_buffer_rsrc_t r = weight_rsrc(ma.w2);
         char* dst = smem + M_W2_OFF + wave * 1024;
-        const bf16_t* src = w2_thr + j * 64;
 #pragma unroll
-        for (int u = 0; u < 6; ++u)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)((u >> 1) * 64 + (u & 1) * 32) * HID),
-                                             (__attribute__((address_space(3))) void*)(dst + u * 4096), 16, 0, 0);
+        for (int u = 0; u < 6; ++u) dma_piece(r, dst + u * 4096, voff_h, (j * 64 + ((u >> 1) * 64 + (u & 1) * 32) * HID) * 2);
     };
 
+    // proj / FC2 accumulators = the residual stream.  Whole-block form: the last head requests the stream's re-read (x as the previous
+    // block -- or patch_embed -- left it) straight into them, so it lands under that head's softmax and the proj accumulates on top;
+    // requested after the proj the 24 loads were a round trip of their own in front of LayerNorm2
+    f32x4 acc2[PROJ ? 2 : 1][PROJ ? 12 : 1];
     B32_STAMP(P_LN1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of head 0's weights; bias staging visible below
     __syncthreads();
@@ -328,9 +386,21 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef TUP_EXP_NOBAR
         __builtin_amdgcn_s_barrier();
+#endif
         if (h + 2 < HEADS) dma_w(h + 2, h & 1);
         else if constexpr (PROJ) dma_wp(h + 2 - HEADS, h & 1);  // proj chunks 0 and 1 take the place of "heads 12 and 13"
+        if constexpr (MLP) {
+            if (h == HEADS - 1) {
+#pragma unroll
+                for (int tg = 0; tg < 2; ++tg) {
+                    const float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
+#pragma unroll
+                    for (int n = 0; n < 12; ++n) acc2[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
+                }
+            }
+        }
         s16x4 kf[4], vf[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -349,7 +419,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) st[tg][kt] = mfma16x16x16(kf[kt], qf[tg], rb[tg][kt]);          // bias as the accumulator input
-        float mx[2], sum[2];
+        float mx[2];
+#ifndef TUP_EXP_NOSOFTMAX      // timing experiment (wrong results): the kernel without the softmax's max / exp arithmetic = the most that
+                               // hiding it under MFMAs could gain (scripts/ab_block.py, DESIGN 5c: -4.5 %); TUP_EXP_NOBAR likewise
+                               // for the per-head barrier (-3.4 %)
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) {
             float m = fmaxf(fmaxf(st[tg][0][0], st[tg][0][1]), fmaxf(st[tg][0][2], st[tg][0][3]));
@@ -360,29 +433,30 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) mx[tg] = rows_max(mx[tg]) * 1.4426950408889634f;
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            float sm = 0.f;
+        for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e)
                     st[tg][kt][e] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[tg][kt][e], 1.4426950408889634f, -mx[tg]));
-                    sm += st[tg][kt][e];
-                }
-            sum[tg] = sm;
-        }
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) sum[tg] = rows_sum(sum[tg]);
+#endif
+        // The row sums come off the matrix pipe: one more product with an all-ones A operand ("a V whose 16 channels are all 1")
+        // leaves sum_k P[q][k] for query column pl in all four of the lane's rows -- the 32 additions per head and lane and the two
+        // cross-lane reductions are 4 MFMAs (the kernel is bound by VALU issue, the pipe has the room); the sum is over the bf16
+        // values that enter the product, i.e. numerator and denominator see the same rounding.
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) {
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+            f32x4 o = {0.f, 0.f, 0.f, 0.f}, sm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
                 const s16x4 p0 = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(st[tg][2 * kp][0], st[tg][2 * kp][1]), pack_bf16x2(st[tg][2 * kp][2], st[tg][2 * kp][3])});
                 const s16x4 p1 = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(st[tg][2 * kp + 1][0], st[tg][2 * kp + 1][1]), pack_bf16x2(st[tg][2 * kp + 1][2], st[tg][2 * kp + 1][3])});
-                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), join4(p0, p1), o);
+                const bf16x8 pj = join4(p0, p1);
+                o = mfma16x16x32(join4(vf[2 * kp], vf[2 * kp + 1]), pj, o);
+                sm = mfma16x16x32(ones, pj, sm);
             }
-            const float inv = __builtin_amdgcn_rcpf(sum[tg]);
+            const float inv = __builtin_amdgcn_rcpf(sm[0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= inv;
             // O^T tile: rows = channel 4g+e, column = query pl  ->  out[row][h*16 + 4g .. +3]
@@ -406,11 +480,12 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     if constexpr (PROJ) {
         // ---- x += att W_proj^T + b: K-step p = heads (2p, 2p+1); the packed weight has its columns ordered to match
         // join4's k map, so the fragment addressing is the standard one (k-tile p >> 1, chunk 4 (p & 1) + g) ----
-        f32x4 acc2[2][12];
+        if constexpr (!MLP) {
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
+            for (int tg = 0; tg < 2; ++tg)
 #pragma unroll
-            for (int n = 0; n < 12; ++n) acc2[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < 12; ++n) acc2[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces of chunk c
@@ -470,85 +545,41 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         } else {
             // ---- second half of the block.  acc2 <- the new residual stream x + proj + b_proj (inactive waves carry a
             // copy of the last window and take part in every barrier; only their final store is skipped) ----
-            // per-channel vector k (0 b_proj, 1 gamma2, 2 beta2, 3 b2) at this lane's channels of accumulator n
+            // per-channel vector k (0 b_proj, 1 b2) at this lane's channels of accumulator n
             const uint32_t vec_addr = sbase + (uint32_t)(M_VEC_OFF + g * 64);
             auto vec4 = [&](int k, int n) {
                 return __builtin_bit_cast(f32x4, lds_read_b128_asm_off(vec_addr, k * (DIM * 4) + ((n >> 2) * 64 + (n & 3) * 4) * 4));
             };
-            {
-                f32x4 rv[2][12];                // the residual stream: all 24 loads in flight before the first use
 #pragma unroll
-                for (int tg = 0; tg < 2; ++tg) {
-#if TUP_FA_FRAG
-                    const float* xf = xio + (size_t)row0 * DIM + lane * 4;
+            for (int q = 0; q < 3; ++q) {          // + b_proj (the residual is already in the accumulators)
+                f32x4 bv[4];
 #pragma unroll
-                    for (int n = 0; n < 12; ++n) rv[tg][n] = *reinterpret_cast<const f32x4*>(xf + (tg * 12 + n) * 256);
-#else
-                    const float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
-#pragma unroll
-                    for (int n = 0; n < 12; ++n) rv[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
-#endif
-                }
+                for (int i = 0; i < 4; ++i) bv[i] = vec4(0, 4 * q + i);
+                lds_wait<0>();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    f32x4 bv[4];
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) bv[i] = vec4(0, 4 * q + i);
-                    lds_wait<0>();
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][4 * q + i] = (acc2[tg][4 * q + i] + bv[i]) + rv[tg][4 * q + i];
-                }
+                    for (int tg = 0; tg < 2; ++tg) acc2[tg][4 * q + i] += bv[i];
             }
             // LayerNorm2 from the accumulators: this lane holds 48 of its token's 192 channels, the other three lane
             // groups the rest.  K-step st of FC1 contracts over channels 64*(st>>1) + 16g + 8*(st&1) .. +8 = accumulators
             // n = 2st, 2st+1 (packing.pack_fc1_fused), so the B fragments are packed straight from them.
+            // gamma2 / beta2 are folded into mlp.0 (packing.fold_layernorm): plain normalised fragments, as LayerNorm1 above
             bf16x8 tf2[2][6];
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
-                float sum = 0.f;             // same summation order as fused_mlp_v2_kernel: the two kernels agree bit for bit
+            for (int tg = 0; tg < 2; ++tg) ln_fragments(acc2[tg], tf2[tg]);
 #pragma unroll
-                for (int st = 0; st < 6; ++st)
+            for (int q = 0; q < 3; ++q) {          // FC2 accumulates onto x + b2
+                f32x4 bv[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) sum += acc2[tg][2 * st][e] + acc2[tg][2 * st + 1][e];
-                sum += __shfl_xor(sum, 16);
-                sum += __shfl_xor(sum, 32);
-                const float mean = sum * (1.0f / DIM);
-                float ss = 0.f;
+                for (int i = 0; i < 4; ++i) bv[i] = vec4(1, 4 * q + i);
+                lds_wait<0>();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int n = 0; n < 12; ++n)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = acc2[tg][n][e] - mean; ss += d * d; }
-                ss += __shfl_xor(ss, 16);
-                ss += __shfl_xor(ss, 32);
-                const float rstd = rsqrtf(ss * (1.0f / DIM) + 1e-5f);
-#pragma unroll
-                for (int st = 0; st < 6; ++st) {
-                    uint32_t pk[4];
-                    f32x4 cv[2][3];            // gamma2, beta2, b2 at channels 64*(st>>1) + 16g + 8*(st&1) + 4hh .. +4 (accumulator 2st+hh)
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) cv[hh][k] = vec4(1 + k, 2 * st + hh);
-                    lds_wait<0>();
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const f32x4 gm = cv[hh][0], bt = cv[hh][1], b2v = cv[hh][2];
-                        const f32x4 v = acc2[tg][2 * st + hh];
-                        float o4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o4[e] = (v[e] - mean) * rstd * gm[e] + bt[e];
-                        pk[2 * hh] = pack_bf16x2(o4[0], o4[1]);
-                        pk[2 * hh + 1] = pack_bf16x2(o4[2], o4[3]);
-                        acc2[tg][2 * st + hh] = v + b2v;               // FC2 accumulates onto x + b2
-                    }
-                    tf2[tg][st] = __builtin_bit_cast(bf16x8, u32x4{pk[0], pk[1], pk[2], pk[3]});
-                }
+                    for (int tg = 0; tg < 2; ++tg) acc2[tg][4 * q + i] += bv[i];
             }
 
             B32_STAMP(P_LN2);
@@ -658,16 +689,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             if (active) {
 #pragma unroll
                 for (int tg = 0; tg < 2; ++tg) {
-#if TUP_FA_FRAG
-                    float* xf = xio + (size_t)row0 * DIM + lane * 4;
-#pragma unroll
-                    for (int n = 0; n < 12; ++n) *reinterpret_cast<f32x4*>(xf + (tg * 12 + n) * 256) = acc2[tg][n];
-#else
                     float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
                     for (int n = 0; n < 12; ++n)
                         *reinterpret_cast<f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4) = acc2[tg][n];
-#endif
                 }
             }
 #pragma unroll
@@ -745,27 +770,33 @@ extern "C" int tup_fused_attn_block_fwd(float* x, const float* gamma, const floa
 }
 
 // One whole WindowTransformerBlock, in place (model.py:153-172): x += proj(attention(qkv(norm1(x)))); x += mlp(norm2(x)).
-// Arguments as tup_fused_attn_block_fwd followed by those of tup_fused_mlp_fwd (w1 packed by packing.pack_fc1_fused).
-extern "C" int tup_fused_block_fwd(float* x, const float* gamma1, const float* beta1, const void* wh, const float* bh,
-                                   const float* bias_frag, const void* wproj, const float* bproj,
-                                   const float* gamma2, const float* beta2, const void* w1, const float* b1,
-                                   const void* w2, const float* b2, int nwin, void* stream)
+// The two LayerNorms' scale and shift arrive FOLDED into the Linear that follows them (packing.fold_layernorm: W diag(gamma),
+// b + W beta -- the same function of x, and the kernel normalises with one FMA per value): wh / bh = packing.pack_qkv_heads of the
+// folded attn.qkv, w1 / b1 = packing.pack_fc1_fused_q of the folded mlp.0; wproj, bproj, w2 (packing.pack_fc2_h4), b2 as in
+// tup_fused_attn_block_fwd / tup_fused_mlp_fwd.
+extern "C" int tup_fused_block_fwd(float* x, const void* wh, const float* bh, const float* bias_frag, const void* wproj,
+                                   const float* bproj, const void* w1, const float* b1, const void* w2, const float* b2,
+                                   int nwin, void* stream)
 {
     if (nwin <= 0) return 0;
-    const MlpArgs ma{gamma2, beta2, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
-    return launch_blocks32(x, one_block(gamma1, beta1, wh, bh, bias_frag, wproj, bproj, ma), 1, nwin, stream);
+    const MlpArgs ma{nullptr, nullptr, (const bf16_t*)w1, b1, (const bf16_t*)w2, b2};
+    return launch_blocks32(x, one_block(nullptr, nullptr, wh, bh, bias_frag, wproj, bproj, ma), 1, nwin, stream);
 }
 
 // nblk (<= 8) consecutive WindowTransformerBlocks, in place, in ONE launch (the loop of model.py:288-289), two waves per window.
-// table: HOST array [nblk][13] of device pointers in the argument order of tup_fused_block_fwd after x
-// (gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2), same packing.
+// table: HOST array [nblk][9] of device pointers in the argument order of tup_fused_block_fwd after x
+// (wh, bh, bias_frag, wproj, bproj, w1, b1, w2, b2), same packing.
 extern "C" int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream)
 {
     if (nwin <= 0 || nblk <= 0) return 0;
     if (nblk > MAX_BLK || table == nullptr) return (int)hipErrorInvalidValue;
-    static_assert(sizeof(BlockPtrs) == 13 * sizeof(void*), "one table row = 13 pointers");
     BlockTable t{};
-    memcpy(&t, table, (size_t)nblk * sizeof(BlockPtrs));
+    for (int i = 0; i < nblk; ++i) {
+        const void* const* r = table + (size_t)i * 9;
+        const MlpArgs ma{nullptr, nullptr, (const bf16_t*)r[5], (const float*)r[6], (const bf16_t*)r[7], (const float*)r[8]};
+        t.b[i] = BlockPtrs{nullptr, nullptr, (const bf16_t*)r[0], (const float*)r[1], (const float*)r[2], (const bf16_t*)r[3],
+                           (const float*)r[4], ma};
+    }
     return launch_blocks32(x, t, nblk, nwin, stream);
 }
 

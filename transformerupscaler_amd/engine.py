@@ -53,21 +53,23 @@ fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
 
 
+def _block_operands(pk, i, bias_frags):
+    """One row of ops.block_table: the whole-block kernels take norm1 / norm2 folded into attn.qkv / mlp.0 (packing.fold_layernorm)."""
+    return (pk[f"b{i}.qkv.whn"], pk[f"b{i}.qkv.bhn"], bias_frags[i], pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"],
+            pk[f"b{i}.fc1.wfqn"], pk[f"b{i}.fc1.bqn"], pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"])
+
+
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
     if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and blocks_in_one_launch:
         # all six blocks in ONE launch (csrc/fused_attn.hip)
-        table = ops.block_table([(pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
-                                  pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
-                                  pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"], pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"]) for i in range(BLOCKS)])
+        table = ops.block_table([_block_operands(pk, i, bias_frags) for i in range(BLOCKS)])
         return ops.fused_blocks32(x, table)
     for i in range(BLOCKS):
         qkv = None
         if fuse_blocks and fuse_attention >= 3 and capture is None and f"b{i}.proj.wpp" in pk:
             # the whole block in one kernel: the residual stream of a token tile stays in registers between the halves
-            ops.fused_block(x, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"], bias_frags[i],
-                            pk[f"b{i}.proj.wpp"], pk[f"b{i}.proj.b"], pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"],
-                            pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"], pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"])
+            ops.fused_block(x, *_block_operands(pk, i, bias_frags))
             continue
         if fuse_blocks and fuse_attention == 2 and capture is None and f"b{i}.proj.wpp" in pk:
             # the whole attention half in one kernel, in place: neither the qkv nor the attention-output tensor exists

@@ -330,18 +330,18 @@ F16 = torch.float16
 
 
 def block_table(blocks):
-    """Pointer table for tup_fused_blocks32_fwd: `blocks` = per block the 13 tensors (gamma1, beta1, wh, bh, bias_frag, wproj,
-    bproj, gamma2, beta2, w1 [= W1 / 4, packing.pack_fc1_fused_q], b1 [= b1 / 4], w2 [= 4 W2 in fp16, packing.pack_fc2_h4], b2),
-    validated here.  Returns (ctypes array [nblk*13] of device pointers, nblk, the tensors -- kept alive by the caller holding
-    the tuple)."""
+    """Pointer table for tup_fused_blocks32_fwd: `blocks` = per block the 9 tensors (wh, bh, bias_frag, wproj, bproj, w1, b1, w2, b2)
+    with norm1 / norm2 folded into attn.qkv / mlp.0 (packing.fold_layernorm), w1 / b1 = mlp.0 / 4 (packing.pack_fc1_fused_q),
+    w2 = 4 W2 in fp16 (packing.pack_fc2_h4), validated here.  Returns (ctypes array [nblk*9] of device pointers, nblk, the
+    tensors -- kept alive by the caller holding the tuple)."""
     import ctypes
-    shapes = [(F32, (192,)), (F32, (192,)), (BF16, (12, 64, 192)), (F32, (12, 48)), (F32, (12, 4, 4, 64, 4)), (BF16, (192, 192)),
-              (F32, (192,)), (F32, (192,)), (F32, (192,)), (BF16, (768, 192)), (F32, (768,)), (F16, (192, 768)), (F32, (192,))]
+    shapes = [(BF16, (12, 64, 192)), (F32, (12, 48)), (F32, (12, 4, 4, 64, 4)), (BF16, (192, 192)), (F32, (192,)),
+              (BF16, (768, 192)), (F32, (768,)), (F16, (192, 768)), (F32, (192,))]
     if not 1 <= len(blocks) <= 8:
         raise ValueError("1..8 blocks per launch")
     ptrs = []
     for blk in blocks:
-        assert len(blk) == 13
+        assert len(blk) == 9
         ptrs += [_chk(t, dt, sh, f"block operand {i}") for i, (t, (dt, sh)) in enumerate(zip(blk, shapes))]
     return ((ctypes.c_void_p * len(ptrs))(*ptrs), len(blocks), [list(b) for b in blocks])
 
@@ -355,15 +355,14 @@ def fused_blocks32(x, table):
     return x
 
 
-def fused_block(x, gamma1, beta1, wh, bh, bias_frag, wproj, bproj, gamma2, beta2, w1, b1, w2, b2):
-    """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion).
-    w1 / b1 = mlp.0 scaled by 1/4 (packing.pack_fc1_fused_q), w2 = 4 mlp.2.weight in fp16 (packing.pack_fc2_h4)."""
+def fused_block(x, wh, bh, bias_frag, wproj, bproj, w1, b1, w2, b2):
+    """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion).  Operands as the
+    rows of block_table: LayerNorm scale / shift folded into wh / bh and w1 / b1 (packing.fold_layernorm)."""
     M = x.shape[0]
     assert M % 64 == 0
-    _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"), _chk(gamma1, F32, (192,), "gamma1"), _chk(beta1, F32, (192,), "beta1"),
+    _lib.call("tup_fused_block_fwd", _chk(x, F32, (M, 192), "x"),
               _chk(wh, BF16, (12, 64, 192), "wh"), _chk(bh, F32, (12, 48), "bh"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
               _chk(wproj, BF16, (192, 192), "wproj"), _chk(bproj, F32, (192,), "bproj"),
-              _chk(gamma2, F32, (192,), "gamma2"), _chk(beta2, F32, (192,), "beta2"),
               _chk(w1, BF16, (768, 192), "w1"), _chk(b1, F32, (768,), "b1"), _chk(w2, F16, (192, 768), "w2"), _chk(b2, F32, (192,), "b2"),
               M // 64, _stream())
     return x

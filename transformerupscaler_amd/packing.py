@@ -126,6 +126,14 @@ def pack_fc2_h4(weight: torch.Tensor):
     return perm_rows64(weight.detach() * 4.0).contiguous().to(torch.float16)
 
 
+def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """Linear(LayerNorm(x)) with the LayerNorm's scale and shift moved into the Linear (model.py:163 norm1 -> attn.qkv, :168 norm2 ->
+    mlp.0): W (xhat * gamma + beta) + b = (W diag(gamma)) xhat + (b + W beta), formed in fp32.  The whole-block kernels
+    (tup_fused_block_fwd, tup_fused_blocks32_fwd) then normalise with one FMA per value and never load gamma / beta."""
+    w = weight.detach().float()
+    return w * gamma.detach().float()[None, :], bias.detach().float() + w @ beta.detach().float()
+
+
 def _fused_k_order(device):
     """Column order of the weights that follow a LayerNorm inside the fused block kernels: K-step st, lane group g, element j
     contracts over channel 64*(st>>1) + 16g + 8*(st&1) + j (the channels whose residual the same lane carries in its accumulators)."""
@@ -290,9 +298,15 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
                 pk[f"b{i}.{nm}.wd"] = wt[i]
     if not backward:      # inference fusion of norm1 + qkv + attention
         for i in range(BLOCKS):
-            pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"window_blocks.{i}.attn.qkv.weight"], sd[f"window_blocks.{i}.attn.qkv.bias"])
-            pk[f"b{i}.proj.wpp"] = pack_proj_pairs(sd[f"window_blocks.{i}.attn.proj.weight"])
-            pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"] = pack_fc1_fused_q(sd[f"window_blocks.{i}.mlp.0.weight"], sd[f"window_blocks.{i}.mlp.0.bias"])
+            p = f"window_blocks.{i}"
+            pk[f"b{i}.qkv.wh"], pk[f"b{i}.qkv.bh"] = pack_qkv_heads(sd[f"{p}.attn.qkv.weight"], sd[f"{p}.attn.qkv.bias"])
+            pk[f"b{i}.proj.wpp"] = pack_proj_pairs(sd[f"{p}.attn.proj.weight"])
+            pk[f"b{i}.fc1.wfq"], pk[f"b{i}.fc1.bq"] = pack_fc1_fused_q(sd[f"{p}.mlp.0.weight"], sd[f"{p}.mlp.0.bias"])
+            # the whole-block kernels: norm1 / norm2 folded into the Linear that follows them
+            pk[f"b{i}.qkv.whn"], pk[f"b{i}.qkv.bhn"] = pack_qkv_heads(*fold_layernorm(
+                sd[f"{p}.attn.qkv.weight"], sd[f"{p}.attn.qkv.bias"], sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"]))
+            pk[f"b{i}.fc1.wfqn"], pk[f"b{i}.fc1.bqn"] = pack_fc1_fused_q(*fold_layernorm(
+                sd[f"{p}.mlp.0.weight"], sd[f"{p}.mlp.0.bias"], sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"]))
             pk[f"b{i}.fc2.wh4"] = pack_fc2_h4(sd[f"window_blocks.{i}.mlp.2.weight"])
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)

@@ -110,8 +110,9 @@ int tup_relpos_bias_expand(const float* table, float* frag, void* stream);
 
 /* WindowAttention core model.py:114-130 (q*scale, qk^T + bias, softmax, @v, head concat).
  * qkv bf16 [nwin][64][576]; out bf16 [nwin][64][192].  drop_p > 0: attn_drop (model.py:80,127) with a
- * stateless hash mask keyed by drop_seed (csrc/common.h); the backward re-derives the same mask. */
-int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, float drop_p,
+ * stateless hash mask keyed by drop_seed (csrc/common.h); the backward re-derives the same mask.
+ * lse: NULL (inference) or fp32 [nwin][12][64] <- log-sum-exp of every score row, saved for tup_window_attn_bwd. */
+int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, float* lse, int nwin, float drop_p,
                         unsigned int drop_seed, void* stream);
 
 /* nn.Linear family model.py:79,81,146-151 with fused epilogues (forward AND the input-gradient
@@ -217,18 +218,20 @@ int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const f
 /* Dense relative-position bias in the second (query-row) fragment order used by the backward. */
 int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream);
 
-/* Attention-core backward (recomputes P): gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] overwritten (the dense
- * gradient of the relative-position bias).  scratch: fp32 [tup_window_attn_bwd_scratch(nwin, heads)], uninitialised -- each
- * persistent wave writes its own partial sum there and a second kernel adds the slots up (no float atomics). */
-int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                        void* gqkv, float* dbias_t, float* scratch, int nwin, float drop_p, unsigned int drop_seed, void* stream);
+/* Attention-core backward: P is rebuilt from q, k, the dense bias (bias_n, tup_relpos_bias_expand_n) and the forward's lse;
+ * rowsum(P dP) = gout . att with att bf16 [nwin][64][192] the forward's output.  gqkv bf16 [nwin][64][576]; dbias_n fp32
+ * [12][4][4][64][4] overwritten (the dense gradient of the relative-position bias, in bias_n's layout).  scratch: fp32
+ * [tup_window_attn_bwd_scratch(nwin, heads)], uninitialised -- each persistent wave writes its own partial sum there and a
+ * second kernel adds the slots up (no float atomics). */
+int tup_window_attn_bwd(const void* qkv, const void* gout, const void* att, const float* lse, const float* bias_n,
+                        void* gqkv, float* dbias_n, float* scratch, int nwin, float drop_p, unsigned int drop_seed, void* stream);
 long long tup_window_attn_bwd_scratch(int nwin, int heads);
 
 /* Backward of nn.Dropout after proj / mlp.2: gout bf16 = gin fp32 * mask / (1 - p), element index m*192+n. */
 int tup_dropout_bwd(const float* gin, void* gout, long long n, float drop_p, unsigned int drop_seed, void* stream);
 
 /* dense bias gradient -> relative_position_bias_table.grad fp32 [225][12] (overwritten). */
-int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream);
+int tup_relpos_bias_reduce(const float* dbias_n, float* dtable, void* stream);
 
 /* Input gradients of patch_unembed (gx fp32 window layout, overwritten) and patch_embed (gmap_pad bf16
  * NHWC [B][ceil8(H)][ceil8(W)][64], the reflect-PADDED map, overwritten). */
@@ -314,8 +317,8 @@ int tup_f32chw_to_u8hwc(const float* src, void* dst, int B, int H, int W, int sw
 int tup_relpos_bias_expand_h(const float* table, float* frag, int heads, void* stream);
 
 /* WindowAttention core (model.py:125-143) for heads x 16 channels: qkv bf16 [nwin][64][48*heads] -> out bf16
- * [nwin][64][16*heads]. */
-int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, void* out, int nwin, int heads, float drop_p,
+ * [nwin][64][16*heads]; lse NULL or fp32 [nwin][heads][64] as tup_window_attn_fwd. */
+int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, void* out, float* lse, int nwin, int heads, float drop_p,
                           unsigned int drop_seed, void* stream);
 
 /* patch_embed (stride-8 conv, no padding: floor(H/8) x floor(W/8) tokens) + permute + zero token pad + window_partition
@@ -337,9 +340,9 @@ int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga
 /* WindowTransformer backward pieces: the FastTransformer entries for `heads` = 8 or 12 and the window-layout patch weight
  * gradient on the floor(H/8) x floor(W/8) token grid (out fp32 [NI][4096] += P^T patches(map), no reflect padding). */
 int tup_relpos_bias_expand_n_h(const float* table, float* frag, int heads, void* stream);
-int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t, const float* bias_n, void* gqkv,
-                          float* dbias_t, float* scratch, int nwin, int heads, float drop_p, unsigned int drop_seed, void* stream);
-int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int heads, void* stream);
+int tup_window_attn_bwd_h(const void* qkv, const void* gout, const void* att, const float* lse, const float* bias_n, void* gqkv,
+                          float* dbias_n, float* scratch, int nwin, int heads, float drop_p, unsigned int drop_seed, void* stream);
+int tup_relpos_bias_reduce_h(const float* dbias_n, float* dtable, int heads, void* stream);
 int tup_wt_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int NI, void* stream);
 
 /* Inference fusion of norm1 + attn.qkv + the WindowAttention core (models/FastTransformer/model.py:104-130,163): the qkv

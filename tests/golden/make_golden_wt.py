@@ -30,7 +30,10 @@ def main():
     # (1) small geometries with every intermediate that matters: token pad (5x7 tokens -> 8x8) and the cropped skip
     #     (H_d = 44 -> 5 token rows = 40 map rows), whole outputs stored
     for tag, shape, kw in (("g88x120_x2", (1, 3, 88, 120), dict(upscale_factor=2)),
-                           ("g128x128_res", (2, 3, 128, 128), dict(res_out=(200, 168)))):
+                           ("g128x128_res", (2, 3, 128, 128), dict(res_out=(200, 168))),
+                           # odd height and width: the stride-2 conv's last output row / column reads its zero padding
+                           # (H_d = 46, W_d = 63 -> 5 x 7 tokens), model.py:205
+                           ("g91x125_res", (1, 3, 91, 125), dict(res_out=(190, 260)))):
         x = torch.rand(shape, generator=torch.Generator().manual_seed(2024))
         caps = {}
         hs = [model.window_blocks[0].register_forward_hook(lambda m, i, o: caps.__setitem__("block0", o.detach().clone())),

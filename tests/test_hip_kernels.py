@@ -243,8 +243,11 @@ def test_window_attention_bwd(dev, det_sd):
     gout = bf(rnd((nwin * 64, 192), 41))
     out.backward(gout)
     tb = table.detach().to(dev)
-    gqkv, dtable = ops.window_attn_bwd(qkv.detach().view(-1, 576).to(torch.bfloat16).to(dev), gout.to(torch.bfloat16).to(dev),
-                                       ops.relpos_bias_expand(tb), ops.relpos_bias_expand_n(tb))
+    qd = qkv.detach().view(-1, 576).to(torch.bfloat16).to(dev)
+    att, lse = ops.window_attn(qd, ops.relpos_bias_expand(tb), save_lse=True)       # the backward rebuilds P from the saved row log-sum-exp
+    ref_lse = torch.logsumexp(attn.detach(), dim=-1)                                # [nwin][12][64]
+    assert (lse.cpu() - ref_lse).abs().max().item() <= 2e-2
+    gqkv, dtable = ops.window_attn_bwd(qd, gout.to(torch.bfloat16).to(dev), att, lse, ops.relpos_bias_expand_n(tb))
     close(gqkv, qkv.grad.view(-1, 576), 2e-2, 2e-2, "attention dqkv")
     close(dtable, table.grad, 5e-2, 2e-2, "dtable")
 

@@ -10,7 +10,8 @@ import torch
 from oracle import window_transformer_oracle as WO
 from transformerupscaler_amd.weights import wt_deterministic_state_dict, wt_param_shapes
 
-CASES = [("g88x120_x2", dict(upscale_factor=2)), ("g128x128_res", dict(res_out=(200, 168)))]
+CASES = [("g88x120_x2", dict(upscale_factor=2)), ("g128x128_res", dict(res_out=(200, 168))),
+         ("g91x125_res", dict(res_out=(190, 260)))]          # odd input size (models/WindowTransformer/model.py:205 accepts it)
 
 
 @pytest.mark.parametrize("tag,kw", CASES)
@@ -93,7 +94,8 @@ def test_oracle_backward_matches_reference_fixture(golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,kw", [((2, 3, 88, 120), dict(upscale_factor=2)), ((1, 3, 144, 160), dict(res_out=(300, 250)))])
+@pytest.mark.parametrize("shape,kw", [((2, 3, 88, 120), dict(upscale_factor=2)), ((1, 3, 144, 160), dict(res_out=(300, 250))),
+                                      ((1, 3, 91, 125), dict(upscale_factor=2))])
 def test_hip_grads_fixed_cotangent_vs_oracle(shape, kw):
     """Every parameter gradient against the oracle's autograd (CPU fp32) with a smooth cotangent; tolerances and their
     calibration as in test_hip_train.py (bf16 activations)."""

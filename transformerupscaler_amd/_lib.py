@@ -32,7 +32,7 @@ SIGNATURES = {
     "tup_clamp01_fwd": [P, P, c_longlong, P],
     "tup_layernorm_fwd": [P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand": [P, P, P],
-    "tup_window_attn_fwd": [P, P, P, I, F, U, P],
+    "tup_window_attn_fwd": [P, P, P, P, I, F, U, P],
     "tup_gemm_tokens_fwd": [P, I, I, P, P, P, P, P, I, I, I, I, I, F, U, P],
     "tup_ln_gemm_fwd": [P, P, P, P, P, P, I, I, P],
     "tup_fused_mlp_fwd": [P, P, P, P, P, P, P, I, P],
@@ -51,10 +51,10 @@ SIGNATURES = {
     "tup_rt_bicubic_bwd_banded": [P] * 7 + [I, P, P, I, P, P, I, I, I, I, I, P, P],
     "tup_relpos_bias_expand_h": [P, P, I, P],
     "tup_relpos_bias_expand_n_h": [P, P, I, P],
-    "tup_window_attn_bwd_h": [P, P, P, P, P, P, P, I, I, F, U, P],
+    "tup_window_attn_bwd_h": [P, P, P, P, P, P, P, P, I, I, F, U, P],
     "tup_relpos_bias_reduce_h": [P, P, I, P],
     "tup_wt_patch_wgrad": [P, P, P, I, I, I, I, P],
-    "tup_window_attn_fwd_h": [P, P, P, I, I, F, U, P],
+    "tup_window_attn_fwd_h": [P, P, P, P, I, I, F, U, P],
     "tup_wt_patch_embed_fwd": [P, P, P, P, I, I, I, I, P],
     "tup_wt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, I, P],
     "tup_fused_qkv_attn_fwd": [P, P, P, P, P, P, P, I, P],
@@ -80,7 +80,7 @@ SIGNATURES = {
     "tup_colsum": [P, I, I, P, I, I, P, P],
     "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],
     "tup_relpos_bias_expand_n": [P, P, P],
-    "tup_window_attn_bwd": [P, P, P, P, P, P, P, I, F, U, P],
+    "tup_window_attn_bwd": [P, P, P, P, P, P, P, P, I, F, U, P],
     "tup_window_attn_bwd_scratch": [I, I],
     "tup_dropout_bwd": [P, P, c_longlong, F, U, P],
     "tup_relpos_bias_reduce": [P, P, P],

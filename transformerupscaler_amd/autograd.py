@@ -69,7 +69,7 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, see
         s = {"x_in": xw}
         s["y1"], s["mean1"], s["rstd1"] = ops.layernorm(xw, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], save_stats=True)
         s["qkv"] = ops.gemm_tokens(s["y1"], pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
-        s["att"] = ops.window_attn(s["qkv"], frags_t[i], drop_p, site_seed(seed, i, 0))
+        s["att"], s["lse"] = ops.window_attn(s["qkv"], frags_t[i], drop_p, site_seed(seed, i, 0), save_lse=True)
         xm = s["x_mid"] = ops.gemm_tokens(s["att"], pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=xw,
                                           drop_p=drop_p, drop_seed=site_seed(seed, i, 1))
         s["y2"], s["mean2"], s["rstd2"] = ops.layernorm(xm, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], save_stats=True)
@@ -166,7 +166,7 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
         g_att = ops.gemm_tokens(g_o, pk[f"b{i}.proj.wd"], None, "bf16")
         del g_o
         g_qkv, g[p + ".attn.relative_position_bias_table"] = ops.window_attn_bwd(
-            s["qkv"], g_att, frags_t[i], frags_n[i], drop_p, site_seed(seed, i, 0))
+            s["qkv"], g_att, s["att"], s["lse"], frags_n[i], drop_p, site_seed(seed, i, 0))
         g[p + ".attn.qkv.weight"], g[p + ".attn.qkv.bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.qkv.wd"], None, "bf16")
         del g_qkv, g_att

@@ -11,6 +11,7 @@ import torch
 
 from . import ops, packing
 from .autograd import site_seed
+from .window_transformer import pad_to_even
 
 
 def _token_rowmask(B, ht, wt, device):
@@ -25,11 +26,11 @@ def _token_rowmask(B, ht, wt, device):
 def forward_train(pk, frags_t, heads, x, res_out, drop_p: float, seed: int):
     B, _, H, W = x.shape
     x = x.contiguous().float()
-    hd, wd = H // 2, W // 2
+    hd, wd = (H + 1) // 2, (W + 1) // 2
     hs, ws = (hd // 8) * 8, (wd // 8) * 8
     sv = {"x": x, "drop_p": drop_p, "seed": seed, "heads": heads}
     feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
-    feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+    feat = pad_to_even(ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True))       # odd sizes: + one zero row / column
     feat_down = ops.conv_c64(feat, pk["ds.w"], pk["ds.b"], 1, relu=False, in_r=2)
     skip = feat_down if (hs, ws) == (hd, wd) else feat_down[:, :hs, :ws, :].contiguous()
     sv["feat1"], sv["feat"], sv["feat_down"], sv["skip"] = feat1, feat, feat_down, skip
@@ -39,7 +40,7 @@ def forward_train(pk, frags_t, heads, x, res_out, drop_p: float, seed: int):
         s = {"x_in": xw}
         y1, s["mean1"], s["rstd1"] = ops.layernorm128(xw, pk[f"b{i}.norm1.w"], pk[f"b{i}.norm1.b"], save_stats=True)
         qkv = ops.gemm_tokens(y1, pk[f"b{i}.qkv.w"], pk[f"b{i}.qkv.b"], "bf16")
-        att = ops.window_attn_h(qkv, frags_t[i], heads, drop_p, site_seed(seed, i, 0))
+        att, s["lse"] = ops.window_attn_h(qkv, frags_t[i], heads, drop_p, site_seed(seed, i, 0), save_lse=True)
         x_mid = ops.gemm_tokens(att, pk[f"b{i}.proj.w"], pk[f"b{i}.proj.b"], "res", res=xw,
                                 drop_p=drop_p, drop_seed=site_seed(seed, i, 1))
         y2, s["mean2"], s["rstd2"] = ops.layernorm128(x_mid, pk[f"b{i}.norm2.w"], pk[f"b{i}.norm2.b"], save_stats=True)
@@ -67,7 +68,7 @@ def backward_train(pk, frags_t, frags_n, sv, gout, reducer=None) -> Dict[str, to
 
     x, heads = sv["x"], sv["heads"]
     B, _, H, W = x.shape
-    hd, wd = H // 2, W // 2
+    hd, wd = (H + 1) // 2, (W + 1) // 2
     hs, ws = sv["skip"].shape[1], sv["skip"].shape[2]
     gout = gout.contiguous().float()
     g_res = ops.rt_bicubic_bwd(gout, sv["out"], (hs, ws))
@@ -103,7 +104,7 @@ def backward_train(pk, frags_t, frags_n, sv, gout, reducer=None) -> Dict[str, to
         g_att = ops.gemm_tokens(g_o, pk[f"b{i}.proj.wd"], None, "bf16")
         del g_o
         g_qkv, g[p + ".attn.relative_position_bias_table"] = ops.window_attn_bwd_h(
-            s["qkv"], g_att, frags_t[i], frags_n[i], heads, drop_p, site_seed(seed, i, 0))
+            s["qkv"], g_att, s["att"], s["lse"], frags_n[i], heads, drop_p, site_seed(seed, i, 0))
         g[p + ".attn.qkv.weight"], g[p + ".attn.qkv.bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.qkv.wd"], None, "bf16")
         del g_qkv, g_att
@@ -128,6 +129,8 @@ def backward_train(pk, frags_t, frags_n, sv, gout, reducer=None) -> Dict[str, to
     g["downsample.weight"], g["downsample.bias"] = packing.unpack_conv_c64_stride2_wgrad(dwp), db
     g_feat = ops.conv_c64(g_fd, pk["ds.wd"], None, 2, mask=sv["feat"])
     del g_fd
+    if g_feat.shape[1:3] != sv["feat1"].shape[1:3]:          # odd input size: drop the zero row / column pad_to_even appended
+        g_feat = g_feat[:, :sv["feat1"].shape[1], :sv["feat1"].shape[2], :].contiguous()
     ready("downsample.weight", "downsample.bias")
     dwp, db = ops.conv_c64_wgrad(sv["feat1"], g_feat, 1)
     g["conv2.weight"], g["conv2.bias"] = packing.unpack_conv_c64_wgrad(dwp, db, 1)

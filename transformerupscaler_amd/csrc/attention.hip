@@ -72,7 +72,7 @@ __global__ void relpos_expand_kernel(const float* __restrict__ table, float* __r
 
 template <int NH>       // heads of 16: 12 (FastTransformer, dim 192) or 8 (WindowTransformer, dim 128)
 __global__ __launch_bounds__(256) void window_attn_kernel(
-    const bf16_t* __restrict__ qkv, const float* __restrict__ bias_frag, bf16_t* __restrict__ out, int npairs,
+    const bf16_t* __restrict__ qkv, const float* __restrict__ bias_frag, bf16_t* __restrict__ out, float* __restrict__ lse, int npairs,
     uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
     constexpr int HEADS = NH, DIM = NH * HD;
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         inv[qt] = 1.0f / sum;
+        // training: the row's log-sum-exp is all the backward needs to rebuild P (csrc/attention_bwd.hip)
+        if (lse != nullptr && active && g == 0) lse[(size_t)pair * NTOK + 16 * qt + p] = mx + __logf(sum);
     }
 
     __syncthreads();   // V staged (per-wave region, but keep it simple: one barrier)
@@ -217,7 +219,8 @@ extern "C" int tup_relpos_bias_expand_h(const float* table, float* frag, int hea
 
 // qkv: bf16 [nwin][64][576] (q | k | v, each head-major 12 x 16); out: bf16 [nwin][64][192].
 // drop_p > 0 applies attn_drop (model.py:80,127) with the stateless mask of common.h keyed by drop_seed.
-extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, int nwin, float drop_p,
+// lse: NULL, or fp32 [nwin][12][64] <- log-sum-exp of every score row (what tup_window_attn_bwd rebuilds P from).
+extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void* out, float* lse, int nwin, float drop_p,
                                    unsigned int drop_seed, void* stream)
 {
     if (nwin <= 0) return 0;
@@ -225,14 +228,14 @@ extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void
     const int npairs = nwin * 12;
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
     window_attn_kernel<12><<<dim3((npairs + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        (const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
     TUP_CHECK_LAUNCH();
     return 0;
 }
 
 // Same kernel for `heads` x 16 channels (8: WindowTransformer, models/WindowTransformer/model.py:67-143): qkv bf16
-// [nwin][64][3*16*heads], out bf16 [nwin][64][16*heads].
-extern "C" int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, void* out, int nwin, int heads, float drop_p,
+// [nwin][64][3*16*heads], out bf16 [nwin][64][16*heads], lse NULL or fp32 [nwin][heads][64].
+extern "C" int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, void* out, float* lse, int nwin, int heads, float drop_p,
                                      unsigned int drop_seed, void* stream)
 {
     if (nwin <= 0) return 0;
@@ -242,9 +245,9 @@ extern "C" int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, vo
     const dim3 grid((npairs + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (heads == 12)
-        window_attn_kernel<12><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        window_attn_kernel<12><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
     else if (heads == 8)
-        window_attn_kernel<8><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        window_attn_kernel<8><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
     else return (int)hipErrorInvalidValue;
     TUP_CHECK_LAUNCH();
     return 0;

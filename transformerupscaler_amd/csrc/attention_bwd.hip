@@ -4,13 +4,14 @@
 //
 // Attention backward: one wave per (window, head), persistent over windows so that the per-head
 // dS sum (the relative-position-bias gradient) accumulates in registers.  Nothing N x N is stored
-// by the forward; P is recomputed from q, k and the dense bias.  Two register orientations of the
-// 64x64 tiles are used so that every product is a v_mfma_f32_16x16x16_bf16 whose B operand is an
-// accumulator tile converted in place:
-//   T-layout (rows = key, cols = query):  dQ^T = K^T dS^T,   dBias += dS^T
-//   N-layout (rows = query, cols = key):  dV^T = dO^T P,     dK^T = Q^T dS
-// Row statistics (max, 1/sum, rowsum(P*dP)) are computed once in the T-layout, where a query is a
-// lane column, and moved to the N-layout with lane shuffles.
+// by the forward: P is recomputed from q, k, the dense bias and the row's log-sum-exp, which the
+// training forward saves (64 floats per window and head); rowsum(P * dP) is dO . O, from the saved
+// attention output.  With both row statistics known up front the 64 x 64 tile is swept ONCE, in the
+//   N-layout (rows = query, cols = key):  dV^T = dO^T P,  dK^T = Q^T dS,  dBias += dS
+// and dQ^T = K^T dS^T takes its B operand from the same dS tiles, written to the wave's LDS as they are
+// produced and read back transposed (ds_read_b64_tr_b16).  (The first form swept the tile twice -- a
+// T-layout pass for the statistics and dQ, then the N-layout pass -- with two exp and two dropout hashes
+// per score and 22 dependent cross-lane shuffles per window: 208 us at 960 windows, one wave per SIMD.)
 #include "common.h"
 
 namespace {
@@ -120,7 +121,8 @@ __global__ void relpos_expand_n_kernel(const float* __restrict__ table, float* _
     frag[idx] = table[rel * HEADS + h];
 }
 
-// dtable[rel][h] = sum over (query, key) pairs with that relative offset of the dense T-layout gradient
+// dtable[rel][h] = sum over (query, key) pairs with that relative offset of the dense N-layout gradient
+// (dfrag[h][qt][kt][lane][e] = d bias(query 16qt + 4(lane >> 4) + e, key 16kt + (lane & 15)), the layout of relpos_expand_n_kernel)
 template <int HEADS>
 __global__ void relpos_reduce_kernel(const float* __restrict__ dfrag, float* __restrict__ dtable)
 {
@@ -136,8 +138,8 @@ __global__ void relpos_reduce_kernel(const float* __restrict__ dfrag, float* __r
             const int qx = kx + dx;
             if (qx < 0 || qx > 7) continue;
             const int qi = qy * 8 + qx, kj = ky * 8 + kx;
-            const int lane = ((kj >> 2) & 3) * 16 + (qi & 15);
-            s += dfrag[((((size_t)h * 4 + (kj >> 4)) * 4 + (qi >> 4)) * 64 + lane) * 4 + (kj & 3)];
+            const int lane = ((qi >> 2) & 3) * 16 + (kj & 15);
+            s += dfrag[((((size_t)h * 4 + (qi >> 4)) * 4 + (kj >> 4)) * 64 + lane) * 4 + (qi & 3)];
         }
     }
     dtable[idx] = s;      // idx = rel*HEADS + h
@@ -155,53 +157,91 @@ TUP_DEVICE s16x4 to_bf16x4(const f32x4 v) {
     return __builtin_bit_cast(s16x4, p);
 }
 
+TUP_DEVICE float dot_bf16x4(const s16x4 a, const s16x4 b) {
+    const u32x2 x = __builtin_bit_cast(u32x2, a), y = __builtin_bit_cast(u32x2, b);
+    float r = __builtin_bit_cast(float, x[0] << 16) * __builtin_bit_cast(float, y[0] << 16);
+    r = __builtin_fmaf(__builtin_bit_cast(float, x[0] & 0xffff0000u), __builtin_bit_cast(float, y[0] & 0xffff0000u), r);
+    r = __builtin_fmaf(__builtin_bit_cast(float, x[1] << 16), __builtin_bit_cast(float, y[1] << 16), r);
+    return __builtin_fmaf(__builtin_bit_cast(float, x[1] & 0xffff0000u), __builtin_bit_cast(float, y[1] & 0xffff0000u), r);
+}
+
 template <int HEADS>
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ gout, const float* __restrict__ bias_t,
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ gout, const bf16_t* __restrict__ att, const float* __restrict__ lse,
     const float* __restrict__ bias_n, bf16_t* __restrict__ gqkv, float* __restrict__ dbias_part, int nwin, int nslots,
     uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
     constexpr int DIM = HEADS * HD;
+    typedef short v4i16 __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) bf16_t lds[4][3][NTOK * HD];     // per wave: K, Q, dO as [tok][hd]
+    __shared__ __attribute__((aligned(16))) bf16_t dsl[4][8][256];           // per wave: dS^T tiles of a query-tile pair, [hh][kt][key 16][query 16]
+    __shared__ __attribute__((aligned(16))) float dl[4][NTOK];               // per wave: rowsum(P * dP) = dO . O per query
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
-    const int gw = blockIdx.x * 4 + wave;
-    const int h = gw % HEADS, slot = gw / HEADS;
     bf16_t* kl = lds[wave][0];
     bf16_t* ql = lds[wave][1];
     bf16_t* dol = lds[wave][2];
-
-    f32x4 dbacc[4][4];
+    // One wave per SIMD (512 registers): a wave = one (slot, head); the head's dense bias (the same for every window of the
+    // persistent wave) and the running dS sum stay in registers.  Measured alternatives at 960 windows, dropout 0.1 (this form:
+    // 142 us for the three launches of the backward): two waves per SIMD by letting hipcc spill 71 registers 198 us; two waves
+    // per SIMD with the bias and the dS sum in LDS (ds_add_f32 from the four waves of a head-workgroup) 340-410 us.
+    const int gw = blockIdx.x * 4 + wave;
+    const int h = gw % HEADS, slot = gw / HEADS;
+    f32x4 dbacc[4][4], bn[4][4];                 // [qt][kt], N layout
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) dbacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < 4; ++kt) {
+            dbacc[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bn[qt][kt] = *reinterpret_cast<const f32x4*>(bias_n + ((((size_t)h * 4 + qt) * 4 + kt) * 64 + lane) * 4);
+        }
 
-    for (int win = slot; win < nwin; win += nslots) {
+    // Everything a window needs from memory: the K, Q, dO rows of this lane's token (for the LDS tiles the transposed fragments are
+    // gathered from), the row fragments [tok 16t+p][d 4g..4g+3] of q, k, v, dO and O, and the log-sum-exp of the lane's 16 query rows.
+    // The NEXT window's set is requested before the current window's arithmetic starts: with one wave per SIMD nothing else covers the
+    // round trip (26 k cycles per window for ~8 k cycles of issue before this).
+    struct WinRegs { u32x4 rows[6]; s16x4 qf[4], kf[4], vf[4], dof[4], of[4]; f32x4 ls[4]; };
+    auto load_window = [&](int win) {
+        WinRegs r;
         const bf16_t* base = qkv + (size_t)win * NTOK * (3 * DIM) + h * HD;
         const bf16_t* gbase = gout + (size_t)win * NTOK * DIM + h * HD;
-        const uint32_t pair = (uint32_t)win * HEADS + h;        // dropout element index = (pair*64 + query)*64 + key
-        // stage K, Q, dO rows (lane = token) for the transposed (gather) fragments
-        {
-            const bf16_t* r = base + (size_t)lane * (3 * DIM);
-            *reinterpret_cast<u32x4*>(ql + lane * HD) = *reinterpret_cast<const u32x4*>(r);
-            *reinterpret_cast<u32x4*>(ql + lane * HD + 8) = *reinterpret_cast<const u32x4*>(r + 8);
-            *reinterpret_cast<u32x4*>(kl + lane * HD) = *reinterpret_cast<const u32x4*>(r + DIM);
-            *reinterpret_cast<u32x4*>(kl + lane * HD + 8) = *reinterpret_cast<const u32x4*>(r + DIM + 8);
-            const bf16_t* gr = gbase + (size_t)lane * DIM;
-            *reinterpret_cast<u32x4*>(dol + lane * HD) = *reinterpret_cast<const u32x4*>(gr);
-            *reinterpret_cast<u32x4*>(dol + lane * HD + 8) = *reinterpret_cast<const u32x4*>(gr + 8);
-        }
-        // row-fragments [tok 16t+p][d 4g..4g+3], usable as A (row = tok) or as B (col = tok)
-        s16x4 qf[4], kf[4], vf[4], dof[4];
+        const bf16_t* abase = att + (size_t)win * NTOK * DIM + h * HD;
+        const bf16_t* rr = base + (size_t)lane * (3 * DIM);
+        const bf16_t* gr = gbase + (size_t)lane * DIM;
+        r.rows[0] = *reinterpret_cast<const u32x4*>(rr);           r.rows[1] = *reinterpret_cast<const u32x4*>(rr + 8);
+        r.rows[2] = *reinterpret_cast<const u32x4*>(rr + DIM);     r.rows[3] = *reinterpret_cast<const u32x4*>(rr + DIM + 8);
+        r.rows[4] = *reinterpret_cast<const u32x4*>(gr);           r.rows[5] = *reinterpret_cast<const u32x4*>(gr + 8);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const size_t roff = (size_t)(16 * t + p) * (3 * DIM) + 4 * g;
-            qf[t] = *reinterpret_cast<const s16x4*>(base + roff);
-            kf[t] = *reinterpret_cast<const s16x4*>(base + roff + DIM);
-            vf[t] = *reinterpret_cast<const s16x4*>(base + roff + 2 * DIM);
-            dof[t] = *reinterpret_cast<const s16x4*>(gbase + (size_t)(16 * t + p) * DIM + 4 * g);
+            r.qf[t] = *reinterpret_cast<const s16x4*>(base + roff);
+            r.kf[t] = *reinterpret_cast<const s16x4*>(base + roff + DIM);
+            r.vf[t] = *reinterpret_cast<const s16x4*>(base + roff + 2 * DIM);
+            r.dof[t] = *reinterpret_cast<const s16x4*>(gbase + (size_t)(16 * t + p) * DIM + 4 * g);
+            r.of[t] = *reinterpret_cast<const s16x4*>(abase + (size_t)(16 * t + p) * DIM + 4 * g);
+            r.ls[t] = *reinterpret_cast<const f32x4*>(lse + ((size_t)win * HEADS + h) * NTOK + 16 * t + 4 * g);
         }
+        return r;
+    };
+    WinRegs nx;
+    if (slot < nwin) nx = load_window(slot);
+    for (int win = slot; win < nwin; win += nslots) {
+        const WinRegs cur = nx;
+        const uint32_t pair = (uint32_t)win * HEADS + h;        // dropout element index = (pair*64 + query)*64 + key
+        // stage K, Q, dO rows (lane = token) for the transposed (gather) fragments
+        *reinterpret_cast<u32x4*>(ql + lane * HD) = cur.rows[0]; *reinterpret_cast<u32x4*>(ql + lane * HD + 8) = cur.rows[1];
+        *reinterpret_cast<u32x4*>(kl + lane * HD) = cur.rows[2]; *reinterpret_cast<u32x4*>(kl + lane * HD + 8) = cur.rows[3];
+        *reinterpret_cast<u32x4*>(dol + lane * HD) = cur.rows[4]; *reinterpret_cast<u32x4*>(dol + lane * HD + 8) = cur.rows[5];
+        s16x4 qf[4], kf[4], vf[4], dof[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            qf[t] = cur.qf[t]; kf[t] = cur.kf[t]; vf[t] = cur.vf[t]; dof[t] = cur.dof[t];
+            // rowsum(P * dP) of query 16t+p = dO . O (O = D(P) V, the saved attention output: holds with dropout, whose mask sits
+            // inside both factors); the four lane groups hold four channels each
+            const float d = rows_sum(dot_bf16x4(dof[t], cur.of[t]));
+            if (g == 0) dl[wave][16 * t + p] = d;
+        }
+        if (win + nslots < nwin) nx = load_window(win + nslots);
         wave_lds_sync();
         // column-fragments [d p][tok 16t+4g+j] (A operands of the transposed products)
         s16x4 kT[4], qT[4], doT[4];
@@ -216,106 +256,71 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
             kT[t] = __builtin_bit_cast(s16x4, a); qT[t] = __builtin_bit_cast(s16x4, b); doT[t] = __builtin_bit_cast(s16x4, c);
         }
 
-        // ---------------- T-layout pass, one query tile (16 columns) at a time ----------------
-        float mrow[4], irow[4], drow[4];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            f32x4 st[4], dpt[4];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const f32x4 bf = *reinterpret_cast<const f32x4*>(bias_t + ((((size_t)h * 4 + kt) * 4 + qt) * 64 + lane) * 4);
-                const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-                dpt[kt] = mfma16x16x16(vf[kt], dof[qt], f32x4{0.f, 0.f, 0.f, 0.f});
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { st[kt][e] = s[e] * 0.25f + bf[e]; mx = fmaxf(mx, st[kt][e]); }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { st[kt][e] = __expf(st[kt][e] - mx); sum += st[kt][e]; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            float dsum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    st[kt][e] *= inv;
-                    if (drop_thresh)     // O = D(P) V with D = mask/keep: dP = mask/keep * (dO V^T)
-                        dpt[kt][e] *= drop_scale(drop_seed, (pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g + e, drop_thresh, drop_inv_keep);
-                    dsum += st[kt][e] * dpt[kt][e];
-                }
-            dsum += __shfl_xor(dsum, 16);
-            dsum += __shfl_xor(dsum, 32);
-            mrow[qt] = mx; irow[qt] = inv; drow[qt] = dsum;
-            f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {
-                s16x4 dsb[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int kt = 2 * kp + hh;
-                    f32x4 ds;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { ds[e] = st[kt][e] * (dpt[kt][e] - dsum); dbacc[kt][qt][e] += ds[e]; }
-                    dsb[hh] = to_bf16x4(ds);
-                }
-                // dQ^T[d][query] += K^T[d][key] dS^T[key][query], two key tiles per MFMA
-                dq = mfma16x16x32(join4(kT[2 * kp], kT[2 * kp + 1]), join4(dsb[0], dsb[1]), dq);
-            }
-            bf16_t* o = gqkv + ((size_t)win * NTOK + 16 * qt + p) * (3 * DIM) + h * HD + 4 * g;
-            *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(dq[0] * 0.25f, dq[1] * 0.25f), pack_bf16x2(dq[2] * 0.25f, dq[3] * 0.25f)};
-        }
-
-        // ---------------- N-layout pass: rows = query 16qt+4g+e, cols = key 16kt+p ----------------
+        // ---------------- N-layout sweep: rows = query 16qt+4g+e, cols = key 16kt+p ----------------
         f32x4 dvT[4], dkT[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) { dvT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dkT[kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {            // dV / dK contract over queries: two query tiles per MFMA
-            float mr[2][4], ir[2][4], dr[2][4];
+            f32x4 l2[2], dd[2];                     // log2(e) * log-sum-exp and dO . O of this lane's four query rows
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    mr[hh][e] = __shfl(mrow[2 * qp + hh], 4 * g + e);
-                    ir[hh][e] = __shfl(irow[2 * qp + hh], 4 * g + e);
-                    dr[hh][e] = __shfl(drow[2 * qp + hh], 4 * g + e);
-                }
+            for (int hh = 0; hh < 2; ++hh) {
+                const int qt = 2 * qp + hh;
+                l2[hh] = cur.ls[qt] * 1.4426950408889634f;
+                dd[hh] = *reinterpret_cast<const f32x4*>(&dl[wave][16 * qt + 4 * g]);
+            }
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 s16x4 prb[2], dsb[2];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int qt = 2 * qp + hh;
-                    const f32x4 bf = *reinterpret_cast<const f32x4*>(bias_n + ((((size_t)h * 4 + qt) * 4 + kt) * 64 + lane) * 4);
+                    const f32x4 bf = bn[qt][kt];
                     const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
                     const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
                     f32x4 pr, ds;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        pr[e] = __expf(s[e] * 0.25f + bf[e] - mr[hh][e]) * ir[hh][e];
+                        pr[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(__builtin_fmaf(s[e], 0.25f, bf[e]), 1.4426950408889634f, -l2[hh][e]));
                         float dpe = dp[e];
-                        if (drop_thresh) {
+                        if (drop_thresh) {     // O = D(P) V with D = mask/keep: dP = mask/keep * (dO V^T)
                             const float m = drop_scale(drop_seed, (pair * 64u + 16u * qt + 4u * g + e) * 64u + 16u * kt + p, drop_thresh, drop_inv_keep);
                             dpe *= m;
-                            ds[e] = pr[e] * (dpe - dr[hh][e]);
+                            ds[e] = pr[e] * (dpe - dd[hh][e]);
                             pr[e] *= m;                    // dV uses the dropped probabilities
                         } else {
-                            ds[e] = pr[e] * (dpe - dr[hh][e]);
+                            ds[e] = pr[e] * (dpe - dd[hh][e]);
                         }
+                        dbacc[qt][kt][e] += ds[e];
                     }
                     prb[hh] = to_bf16x4(pr);
                     dsb[hh] = to_bf16x4(ds);
+                    // the same tile as [key p][query 4g .. 4g+3]: 32-byte rows, read back transposed below
+                    *reinterpret_cast<s16x4*>(&dsl[wave][hh * 4 + kt][p * 16 + 4 * g]) = dsb[hh];
                 }
                 dvT[kt] = mfma16x16x32(join4(doT[2 * qp], doT[2 * qp + 1]), join4(prb[0], prb[1]), dvT[kt]);   // dV^T += dO^T P
                 dkT[kt] = mfma16x16x32(join4(qT[2 * qp], qT[2 * qp + 1]), join4(dsb[0], dsb[1]), dkT[kt]);     // dK^T += Q^T dS
             }
+            wave_lds_sync();
+            // dQ^T[d][query] = K^T[d][key] dS^T[key][query], two key tiles per MFMA; the B fragment of lane (g, p) = dS[query p][keys
+            // 4g .. 4g+3] = column p of rows 4g .. 4g+3 of the stored [key][query] tile: the transposing LDS read
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int qt = 2 * qp + hh;
+                f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    s16x4 t[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        t[u] = __builtin_bit_cast(s16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) v4i16*)&dsl[wave][hh * 4 + 2 * kp + u][(4 * g + (p >> 2)) * 16 + (p & 3) * 4]));
+                    dq = mfma16x16x32(join4(kT[2 * kp], kT[2 * kp + 1]), join4(t[0], t[1]), dq);
+                }
+                bf16_t* o = gqkv + ((size_t)win * NTOK + 16 * qt + p) * (3 * DIM) + h * HD + 4 * g;
+                *reinterpret_cast<u32x2*>(o) = u32x2{pack_bf16x2(dq[0] * 0.25f, dq[1] * 0.25f), pack_bf16x2(dq[2] * 0.25f, dq[3] * 0.25f)};
+            }
+            wave_lds_sync();      // the dS tiles are overwritten by the next pair
         }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -327,15 +332,15 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
         wave_lds_sync();      // LDS tiles are overwritten by the next window
     }
 
-    // this wave's dS sum goes to ITS OWN slice of the scratch buffer with plain stores ([slot][h][kt][qt][lane][4]); the slots are
-    // summed by dbias_sum_kernel.  (Float atomics straight into dbias_t -- every wave of a head adding to the same 4,096
-    // addresses, 128-way -- were 49 of the kernel's 245 us.)
+    // the dS sum goes to this wave's (workgroup's) OWN slice of the scratch buffer with plain stores ([part][h][qt][kt][lane][4]); the
+    // parts are summed by dbias_sum_kernel.  (Float atomics straight into the dense gradient -- every wave of a head adding to the
+    // same 4,096 addresses, 128-way -- were 49 of the kernel's 245 us.)
     float* part = dbias_part + ((size_t)slot * HEADS + h) * 4096;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-            *reinterpret_cast<f32x4*>(part + (((size_t)kt * 4 + qt) * 64 + lane) * 4) = dbacc[kt][qt];
+        for (int kt = 0; kt < 4; ++kt)
+            *reinterpret_cast<f32x4*>(part + (((size_t)qt * 4 + kt) * 64 + lane) * 4) = dbacc[qt][kt];
 }
 
 // gd = g * mask/keep (element index m*192 + n): gradient through proj_drop / the MLP's Dropout
@@ -413,8 +418,8 @@ extern "C" int tup_relpos_bias_expand_n(const float* table, float* frag, void* s
 }
 
 namespace {
-// dbias_t[i] = sum over slots of part[slot][i], i < n4 float4s: 64 float4 columns x 4 slot groups per workgroup, LDS-combined
-__global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict__ part, float* __restrict__ dbias_t, int n4, int nslots)
+// dbias_n[i] = sum over slots of part[slot][i], i < n4 float4s: 64 float4 columns x 4 slot groups per workgroup, LDS-combined
+__global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict__ part, float* __restrict__ dbias_n, int n4, int nslots)
 {
     __shared__ f32x4 red[4][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
@@ -424,33 +429,40 @@ __global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict_
     red[grp][threadIdx.x & 63] = acc;
     __syncthreads();
     if (grp == 0 && col < n4)
-        reinterpret_cast<f32x4*>(dbias_t)[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        reinterpret_cast<f32x4*>(dbias_n)[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-constexpr int ATTN_BWD_MAX_SLOTS = 128;
-inline int attn_bwd_slots(int nwin) { return nwin < ATTN_BWD_MAX_SLOTS ? nwin : ATTN_BWD_MAX_SLOTS; }
+// Persistent waves per head: one wave per (slot, head), one wave per SIMD -- the grid is sized to ONE resident set of the chip
+// (256 CUs x 4 SIMDs = 1,024 waves: 85 slots x 12 heads).  128 slots were 1.5 resident sets, i.e. two rounds with half of the chip
+// idle in the second: 186 -> 154 us.  TUP_ATTN_BWD_SLOTS overrides (timing experiments).
+inline int attn_bwd_slots(int nwin, int heads)
+{
+    static const int forced = [] { const char* e = getenv("TUP_ATTN_BWD_SLOTS"); return e ? atoi(e) : 0; }();
+    const int cap = forced > 0 ? forced : 1024 / heads;
+    return nwin < cap ? nwin : cap;
+}
 
 template <int HEADS>
-int launch_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n, void* gqkv, float* dbias_t,
-                    float* scratch, int nwin, float drop_p, unsigned int drop_seed, hipStream_t s)
+int launch_attn_bwd(const void* qkv, const void* gout, const void* att, const float* lse, const float* bias_n, void* gqkv,
+                    float* dbias_n, float* scratch, int nwin, float drop_p, unsigned int drop_seed, hipStream_t s)
 {
-    if (scratch == nullptr) return (int)hipErrorInvalidValue;
+    if (scratch == nullptr || att == nullptr || lse == nullptr) return (int)hipErrorInvalidValue;
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    const int nslots = attn_bwd_slots(nwin);
+    const int nslots = attn_bwd_slots(nwin, HEADS);
     const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
     window_attn_bwd_kernel<HEADS><<<dim3(nwaves / 4), dim3(256), 0, s>>>(
-        (const bf16_t*)qkv, (const bf16_t*)gout, bias_t, bias_n, (bf16_t*)gqkv, scratch, nwin, nslots,
+        (const bf16_t*)qkv, (const bf16_t*)gout, (const bf16_t*)att, lse, bias_n, (bf16_t*)gqkv, scratch, nwin, nslots,
         thresh, 1.0f / (1.0f - drop_p), drop_seed);
     TUP_CHECK_LAUNCH();
     const int n4 = HEADS * 1024;
-    dbias_sum_kernel<<<dim3(n4 / 64), dim3(256), 0, s>>>(scratch, dbias_t, n4, nslots);
+    dbias_sum_kernel<<<dim3(n4 / 64), dim3(256), 0, s>>>(scratch, dbias_n, n4, nslots);
     TUP_CHECK_LAUNCH();
     return 0;
 }
 }  // namespace
 
 // The same three entry points for `heads` = 8 (WindowTransformer, width 128) or 12: table / dtable fp32 [225][heads],
-// frag / dbias_t fp32 [heads][4][4][64][4], qkv / gqkv bf16 [nwin][64][48*heads], gout bf16 [nwin][64][16*heads].
+// frag / dbias_n fp32 [heads][4][4][64][4], qkv / gqkv bf16 [nwin][64][48*heads], gout bf16 [nwin][64][16*heads].
 extern "C" int tup_relpos_bias_expand_n_h(const float* table, float* frag, int heads, void* stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -461,50 +473,51 @@ extern "C" int tup_relpos_bias_expand_n_h(const float* table, float* frag, int h
     return 0;
 }
 
-extern "C" int tup_window_attn_bwd_h(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                                     void* gqkv, float* dbias_t, float* scratch, int nwin, int heads, float drop_p,
+extern "C" int tup_window_attn_bwd_h(const void* qkv, const void* gout, const void* att, const float* lse, const float* bias_n,
+                                     void* gqkv, float* dbias_n, float* scratch, int nwin, int heads, float drop_p,
                                      unsigned int drop_seed, void* stream)
 {
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (heads == 12) return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, scratch, nwin, drop_p, drop_seed, s);
-    if (heads == 8) return launch_attn_bwd<8>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, scratch, nwin, drop_p, drop_seed, s);
+    if (heads == 12) return launch_attn_bwd<12>(qkv, gout, att, lse, bias_n, gqkv, dbias_n, scratch, nwin, drop_p, drop_seed, s);
+    if (heads == 8) return launch_attn_bwd<8>(qkv, gout, att, lse, bias_n, gqkv, dbias_n, scratch, nwin, drop_p, drop_seed, s);
     return (int)hipErrorInvalidValue;
 }
 
-extern "C" int tup_relpos_bias_reduce_h(const float* dbias_t, float* dtable, int heads, void* stream)
+extern "C" int tup_relpos_bias_reduce_h(const float* dbias_n, float* dtable, int heads, void* stream)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (heads == 12) relpos_reduce_kernel<12><<<dim3((225 * 12 + 255) / 256), dim3(256), 0, s>>>(dbias_t, dtable);
-    else if (heads == 8) relpos_reduce_kernel<8><<<dim3((225 * 8 + 255) / 256), dim3(256), 0, s>>>(dbias_t, dtable);
+    if (heads == 12) relpos_reduce_kernel<12><<<dim3((225 * 12 + 255) / 256), dim3(256), 0, s>>>(dbias_n, dtable);
+    else if (heads == 8) relpos_reduce_kernel<8><<<dim3((225 * 8 + 255) / 256), dim3(256), 0, s>>>(dbias_n, dtable);
     else return (int)hipErrorInvalidValue;
     TUP_CHECK_LAUNCH();
     return 0;
 }
 
-// qkv bf16 [nwin][64][576], gout bf16 [nwin][64][192] (grad of the attention output before proj) ->
-// gqkv bf16 [nwin][64][576]; dbias_t fp32 [12][4][4][64][4] overwritten; scratch fp32 [tup_window_attn_bwd_scratch(nwin, 12)]
-// (per-wave partial sums of the bias gradient, no initialisation needed).
-extern "C" int tup_window_attn_bwd(const void* qkv, const void* gout, const float* bias_t, const float* bias_n,
-                                   void* gqkv, float* dbias_t, float* scratch, int nwin, float drop_p, unsigned int drop_seed,
+// qkv bf16 [nwin][64][576], gout bf16 [nwin][64][192] (grad of the attention output before proj), att bf16 [nwin][64][192] (that
+// output) and lse fp32 [nwin][12][64] (log-sum-exp of every score row), both as tup_window_attn_fwd left them -> gqkv bf16
+// [nwin][64][576]; dbias_n fp32 [12][4][4][64][4] (dense bias gradient in the layout of tup_relpos_bias_expand_n) overwritten;
+// scratch fp32 [tup_window_attn_bwd_scratch(nwin, 12)] (per-wave partial sums of the bias gradient, no initialisation needed).
+extern "C" int tup_window_attn_bwd(const void* qkv, const void* gout, const void* att, const float* lse, const float* bias_n,
+                                   void* gqkv, float* dbias_n, float* scratch, int nwin, float drop_p, unsigned int drop_seed,
                                    void* stream)
 {
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
-    return launch_attn_bwd<12>(qkv, gout, bias_t, bias_n, gqkv, dbias_t, scratch, nwin, drop_p, drop_seed, reinterpret_cast<hipStream_t>(stream));
+    return launch_attn_bwd<12>(qkv, gout, att, lse, bias_n, gqkv, dbias_n, scratch, nwin, drop_p, drop_seed, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Floats of scratch tup_window_attn_bwd(_h) needs for nwin windows and `heads` heads.
 extern "C" long long tup_window_attn_bwd_scratch(int nwin, int heads)
 {
-    return nwin <= 0 ? 0 : (long long)attn_bwd_slots(nwin) * heads * 4096;
+    return nwin <= 0 ? 0 : (long long)attn_bwd_slots(nwin, heads) * heads * 4096;
 }
 
-// dense T-layout bias gradient -> relative_position_bias_table gradient fp32 [225][12] (overwritten).
-extern "C" int tup_relpos_bias_reduce(const float* dbias_t, float* dtable, void* stream)
+// dense N-layout bias gradient (tup_window_attn_bwd) -> relative_position_bias_table gradient fp32 [225][12] (overwritten).
+extern "C" int tup_relpos_bias_reduce(const float* dbias_n, float* dtable, void* stream)
 {
-    relpos_reduce_kernel<12><<<dim3((225 * 12 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(dbias_t, dtable);
+    relpos_reduce_kernel<12><<<dim3((225 * 12 + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(dbias_n, dtable);
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -862,7 +862,9 @@ extern "C" int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float*
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const size_t lds = ((size_t)3 * (th + 2) * HALO_W + (size_t)cout * th * 32 + (size_t)r * r * 84) * sizeof(float);
-    const dim3 grid(persistent_grid(nt, 4));
+    // persistent workgroups, one resident set: the r = 2 instance holds 132 registers = three workgroups per CU (four were 1,024
+    // workgroups on 768 slots: 1.33 rounds, scripts/grid_rounds.py), the others four
+    const dim3 grid(persistent_grid(nt, r == 2 ? 3 : 4));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (r == 1) conv3x3_wgrad_planar_kernel<1, 32><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
     else if (r == 2) conv3x3_wgrad_planar_kernel<2, 16><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);

@@ -253,7 +253,10 @@ int launch(WgradParams p, hipStream_t s)
     if (p.M <= 0) return 0;
     if (p.NI % 64 || p.NJ % 64) return (int)hipErrorInvalidValue;
     const int blocks_ij = (p.NI / 64) * (p.NJ / 64);
-    int msplit = (1024 + blocks_ij - 1) / blocks_ij;
+    // Five workgroups per CU are resident (32 KB of LDS each, 52 registers): any grid up to 1,280 workgroups is one round; the
+    // split is rounded DOWN so that the M slices never come out shorter than the target (more slices = more fp32 atomics on the
+    // same 64 x 64 output tiles; the kernel is bound by L2 reads of its operands)
+    int msplit = 1024 / blocks_ij;
     const int maxsplit = (p.M + 63) / 64;
     if (msplit > maxsplit) msplit = maxsplit;
     if (msplit < 1) msplit = 1;

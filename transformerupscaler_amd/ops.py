@@ -262,13 +262,16 @@ def relpos_bias_expand(table):
     return frag
 
 
-def window_attn(qkv, bias_frag, drop_p=0.0, drop_seed=0):
+def window_attn(qkv, bias_frag, drop_p=0.0, drop_seed=0, save_lse=False):
+    """WindowAttention core.  save_lse (training): also returns the fp32 [M // 64][12][64] log-sum-exp of every score row, which
+    window_attn_bwd rebuilds the probabilities from."""
     M, D = qkv.shape
     assert D == 576 and M % 64 == 0
     out = torch.empty((M, 192), dtype=BF16, device=qkv.device)
+    lse = torch.empty((M // 64, 12, 64), dtype=F32, device=qkv.device) if save_lse else None
     _lib.call("tup_window_attn_fwd", _chk(qkv, BF16, None, "qkv"), _chk(bias_frag, F32, (12, 4, 4, 64, 4), "bias"),
-              out.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
-    return out
+              out.data_ptr(), lse.data_ptr() if save_lse else None, M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+    return (out, lse) if save_lse else out
 
 
 def gemm_tokens(a, wt, bias, epilogue, res=None, out=None, aux=None, drop_p=0.0, drop_seed=0):
@@ -482,15 +485,15 @@ def _attn_bwd_scratch(nwin, heads):
     return int(fn(int(nwin), int(heads)))
 
 
-def window_attn_bwd(qkv, gout, bias_t, bias_n, drop_p=0.0, drop_seed=0):
-    """returns (gqkv bf16 [M][576], dtable fp32 [225][12])."""
+def window_attn_bwd(qkv, gout, att, lse, bias_n, drop_p=0.0, drop_seed=0):
+    """att, lse: what window_attn(..., save_lse=True) returned.  Returns (gqkv bf16 [M][576], dtable fp32 [225][12])."""
     M = qkv.shape[0]
     assert M % 64 == 0
     gqkv = torch.empty((M, 576), dtype=BF16, device=qkv.device)
     dbias = torch.empty((12, 4, 4, 64, 4), dtype=F32, device=qkv.device)
     scratch = torch.empty(_attn_bwd_scratch(M // 64, 12), dtype=F32, device=qkv.device)
     _lib.call("tup_window_attn_bwd", _chk(qkv, BF16, (M, 576), "qkv"), _chk(gout, BF16, (M, 192), "gout"),
-              _chk(bias_t, F32, (12, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (12, 4, 4, 64, 4), "bias_n"),
+              _chk(att, BF16, (M, 192), "att"), _chk(lse, F32, (M // 64, 12, 64), "lse"), _chk(bias_n, F32, (12, 4, 4, 64, 4), "bias_n"),
               gqkv.data_ptr(), dbias.data_ptr(), scratch.data_ptr(), M // 64, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     dtable = torch.empty((225, 12), dtype=F32, device=qkv.device)
     _lib.call("tup_relpos_bias_reduce", dbias.data_ptr(), dtable.data_ptr(), _stream())
@@ -949,13 +952,14 @@ def relpos_bias_expand_h(table, heads):
     return frag
 
 
-def window_attn_h(qkv, bias_frag, heads, drop_p=0.0, drop_seed=0):
+def window_attn_h(qkv, bias_frag, heads, drop_p=0.0, drop_seed=0, save_lse=False):
     M, D = qkv.shape
     assert D == 48 * heads and M % 64 == 0
     out = torch.empty((M, 16 * heads), dtype=BF16, device=qkv.device)
+    lse = torch.empty((M // 64, heads, 64), dtype=F32, device=qkv.device) if save_lse else None
     _lib.call("tup_window_attn_fwd_h", _chk(qkv, BF16, None, "qkv"), _chk(bias_frag, F32, (heads, 4, 4, 64, 4), "bias"),
-              out.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
-    return out
+              out.data_ptr(), lse.data_ptr() if save_lse else None, M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
+    return (out, lse) if save_lse else out
 
 
 def wt_patch_embed(feat, wt, bias):
@@ -1001,7 +1005,7 @@ def relpos_bias_expand_n_h(table, heads):
     return frag
 
 
-def window_attn_bwd_h(qkv, gout, bias_t, bias_n, heads, drop_p=0.0, drop_seed=0):
+def window_attn_bwd_h(qkv, gout, att, lse, bias_n, heads, drop_p=0.0, drop_seed=0):
     """returns (gqkv bf16 [M][48*heads], dtable fp32 [225][heads])."""
     M = qkv.shape[0]
     assert M % 64 == 0
@@ -1009,7 +1013,8 @@ def window_attn_bwd_h(qkv, gout, bias_t, bias_n, heads, drop_p=0.0, drop_seed=0)
     dbias = torch.empty((heads, 4, 4, 64, 4), dtype=F32, device=qkv.device)
     scratch = torch.empty(_attn_bwd_scratch(M // 64, heads), dtype=F32, device=qkv.device)
     _lib.call("tup_window_attn_bwd_h", _chk(qkv, BF16, (M, 48 * heads), "qkv"), _chk(gout, BF16, (M, 16 * heads), "gout"),
-              _chk(bias_t, F32, (heads, 4, 4, 64, 4), "bias_t"), _chk(bias_n, F32, (heads, 4, 4, 64, 4), "bias_n"),
+              _chk(att, BF16, (M, 16 * heads), "att"), _chk(lse, F32, (M // 64, heads, 64), "lse"),
+              _chk(bias_n, F32, (heads, 4, 4, 64, 4), "bias_n"),
               gqkv.data_ptr(), dbias.data_ptr(), scratch.data_ptr(), M // 64, heads, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _stream())
     dtable = torch.empty((225, heads), dtype=F32, device=qkv.device)
     _lib.call("tup_relpos_bias_reduce_h", dbias.data_ptr(), dtable.data_ptr(), heads, _stream())

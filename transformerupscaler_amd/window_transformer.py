@@ -21,6 +21,16 @@ from . import ops, packing
 from .fast_transformer import WindowTransformerBlock, _ConvParams
 
 
+def pad_to_even(feat: torch.Tensor) -> torch.Tensor:
+    """NHWC map with an odd height / width -> one zero row / column appended.  The stride-2, pad-1 conv of the reference
+    (models/WindowTransformer/model.py:205) reads input row H only through its zero padding, so on the padded map the even-size
+    kernel computes exactly the reference's ceil(H / 2) x ceil(W / 2) outputs."""
+    B, H, W, C = feat.shape
+    if H % 2 == 0 and W % 2 == 0:
+        return feat
+    return torch.nn.functional.pad(feat, (0, 0, 0, W % 2, 0, H % 2))
+
+
 class TransformerModel(nn.Module):
     def __init__(self, in_channels: int = 3, base_channels: int = 64, transformer_dim: int = 128, num_window_blocks: int = 8,
                  num_heads: int = 8, mlp_ratio: float = 4.0, dropout: float = 0.01, window_size: int = 8):
@@ -80,9 +90,7 @@ class TransformerModel(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("TransformerModel (MI355X build) runs on the GPU only; there is no CPU fallback.")
         B, _, H, W = x.shape
-        if H % 2 or W % 2:
-            raise NotImplementedError("odd input sizes (the stride-2 conv's ragged last row) are not built")
-        hd, wd = H // 2, W // 2
+        hd, wd = (H + 1) // 2, (W + 1) // 2             # the stride-2, pad-1 conv: ceil(H / 2) x ceil(W / 2), model.py:205,244
         if hd < 8 or wd < 8:
             raise RuntimeError("input too small for one 8x8 patch after the stride-2 conv")    # the reference's conv fails too
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -98,7 +106,7 @@ class TransformerModel(nn.Module):
         pk, frags = self.packed()
         x = x.contiguous().float()
         feat = ops.conv_c64(ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True), pk["conv2.w"], pk["conv2.b"], 1, relu=True)
-        feat_down = ops.conv_c64(feat, pk["ds.w"], pk["ds.b"], 1, relu=False, in_r=2)        # model.py:244
+        feat_down = ops.conv_c64(pad_to_even(feat), pk["ds.w"], pk["ds.b"], 1, relu=False, in_r=2)        # model.py:244
         del feat
         xw = ops.wt_patch_embed(feat_down, pk["pe.w"], pk["pe.b"])                          # model.py:247-268
         heads = self.num_heads

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Join two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, guide MI355X_MICROARCH.md 'HBM') and a --kernel-trace
---stats pass of the same bench command into profiles/r02_pmc_traffic.json: per kernel the HBM-side bytes per launch
+--stats pass of the same bench command into profiles/r03_pmc_traffic_<mode>.json: per kernel the HBM-side bytes per launch
 (FETCH_SIZE x 2 on gfx950 for wide coalesced reads + WRITE_SIZE, both reported in KB) and the rate at the traced duration.
 Each entry records the sha256 of the kernel's source file; bench.py reports `traffic` only while that still matches.
 
@@ -31,7 +31,7 @@ KEYS = {
         "branch_a_5x5": ("conv_c64_persistent_kernel<1, 1, 5>", "conv3x3_c64.hip", 4 * 1080 * 1920 * 64 * 2 + 4 * 3 * 2160 * 3840 * 4),
     },
     "train": {   # B = 4, 2x 720p -> 1080p training step
-        "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 192 * 2 + 576 * 2)),      # qkv + d att in, d qkv out
+        "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 2 * 192 * 2 + 576 * 2) + 960 * 12 * 64 * 4),      # qkv, d att, att, lse in; d qkv out
         "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 4 * F64),
         "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip", 2 * 4 * F64),
         "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),

@@ -373,12 +373,14 @@ extern "C" int tup_dropout_bwd(const float* gin, void* gout, long long n, float 
 }
 
 namespace {
-// 16 rows per block and sweep; the grid is the number of row groups divided by the smallest sweep count that fits 1,280 blocks
-// (five per CU), so every block runs the same number of sweeps (61,440 rows: 1,280 blocks x 3 instead of 1,024 x 3.75)
+// 16 rows per block and sweep.  Every workgroup ends with 2 x 192 float atomics onto the SAME dgamma / dbeta addresses, and those
+// serialise in L2: at 61,440 rows 1,280 workgroups took 95 us per call, 256 take 57 us (same box, incl. the two memsets) -- the grid
+// is one workgroup per CU, every workgroup the same number of sweeps.  TUP_LN_BWD_BLOCKS overrides (timing experiments).
 int ln_bwd_blocks(int M)
 {
+    static const int cap = [] { const char* e = getenv("TUP_LN_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
     const int groups = (M + 15) / 16;
-    const int sweeps = (groups + 1279) / 1280;
+    const int sweeps = (groups + cap - 1) / cap;
     return (groups + sweeps - 1) / sweeps;
 }
 }  // namespace

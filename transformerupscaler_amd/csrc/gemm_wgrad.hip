@@ -199,7 +199,11 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradParams p)
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
+#ifndef TUP_EXP_NOATOMIC      // timing experiment (wrong results)
             atomicAdd(p.out + (size_t)(i0 + 16 * wave + 4 * g + e) * p.ldo + j0 + 16 * jt + l16, acc[jt][e]);
+#else
+            if (acc[jt][e] == 123.456f) p.out[0] = 1.f;
+#endif
     if (want_cs && l16 == 0) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) atomicAdd(p.colsum_out + i0 + 16 * wave + 4 * g + e, accs[e]);
@@ -221,7 +225,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G,
     float acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
-    for (int m = mbeg + lr; m < mend; m += RPB) {
+    int m = mbeg + lr;
+    if constexpr (!F32) if (rowmask == nullptr) {
+        // the 472 MB bias-gradient sums of the 64-channel maps: four rows in flight per lane (one dependent load per iteration ran the
+        // stream at 3.9 TB/s)
+        const bf16_t* gp = (const bf16_t*)G;
+        for (; m + 3 * RPB < mend; m += 4 * RPB) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(gp + (size_t)(m + u * RPB) * ld + n);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[2 * q] += __builtin_bit_cast(float, v[u][q] << 16);
+                    acc[2 * q + 1] += __builtin_bit_cast(float, v[u][q] & 0xffff0000u);
+                }
+        }
+    }
+    for (; m < mend; m += RPB) {
         if (rowmask && !rowmask[m]) continue;
         if constexpr (F32) {
             const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)G + (size_t)m * ld + n);
@@ -342,7 +364,11 @@ extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, i
 {
     if (M <= 0 || N <= 0) return 0;
     if (N % 64 != 0 || ld % 8 != 0) return (int)hipErrorInvalidValue;
-    int msplit = 2048 / (N / 64);
+    // every workgroup ends with 64 float atomics on the same addresses (they serialise in L2): a few hundred workgroups, not thousands
+    // (the 64-column map sums: 2,048 workgroups 106 us, 512 95 us; three column stripes of token rows are flat from 512 to 2,048)
+    static const int forced = [] { const char* e = getenv("TUP_COLSUM_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int target = forced > 0 ? forced : (N == 64 ? 512 : 2048);
+    int msplit = target / (N / 64);
     if (msplit < 1) msplit = 1;
     int mchunk = (M + msplit - 1) / msplit;
     if (mchunk < 256) mchunk = 256;

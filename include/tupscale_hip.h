@@ -65,7 +65,9 @@ int tup_conv3x3_planar_fwd(const float* x, const float* w28, const float* bias, 
                            float* out, int B, int H, int W, int r, int clamp01, void* stream);
 
 /* transforms.Resize on a tensor = antialiased bilinear (model.py:323-325, train.py:127-130)
- * [+ clamp(0,1) model.py:327].  Tap tables as aten's _compute_indices_weights_aa (float32). */
+ * [+ clamp(0,1) model.py:327].  Tap tables as aten's _compute_indices_weights_aa (float32).
+ * clamp01: 0 = out is the resized tensor; 1 = clamped; 2 (training) = out is [2][planes][Ho][Wo]: first the unclamped values
+ * (the gate of the clamp's backward), then the clamped ones (the model output), written in the same pass. */
 int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, const int* ysize, const float* yw,
                       int KY, const int* xmin, const int* xsize, const float* xw, int KX, int planes,
                       int Hi, int Wi, int Ho, int Wo, int clamp01, void* stream);
@@ -210,10 +212,12 @@ int tup_patch_wgrad(const float* P, const void* map, float* out, int B, int H, i
  * rowmask[m] != 0 (uint8 [M]; NULL = all rows). */
 int tup_colsum(const void* G, int dtype, int ld, float* out, int M, int N, const void* rowmask, void* stream);
 
-/* LayerNorm backward: dx = LN'(gy) (+ gres), dgamma/dbeta fp32 [192] +=. */
+/* LayerNorm backward: dx = LN'(gy) (+ gres), dgamma/dbeta fp32 [192] +=.  gdrop: NULL, or bf16 [M][192] <- dx * dropout mask /
+ * (1 - drop_p) for the site keyed by drop_seed (tup_dropout_bwd of dx fused in: the gradient's next stop is the Dropout behind
+ * attn.proj / mlp.2, model.py:82,132,150). */
 int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
                       const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
-                      int M, void* stream);
+                      int M, void* gdrop, float drop_p, unsigned int drop_seed, void* stream);
 
 /* Dense relative-position bias in the second (query-row) fragment order used by the backward. */
 int tup_relpos_bias_expand_n(const float* table, float* frag, void* stream);
@@ -272,7 +276,8 @@ int tup_feat_grad_combine(const void* a, const void* b, const void* gpe, const v
 
 /* LayerNorm(128) backward; same contract as tup_layernorm_bwd (dgamma / dbeta fp32 [128] accumulated). */
 int tup_layernorm128_bwd(const void* gy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                         const float* gres, float* dx, float* dgamma, float* dbeta, int M, void* stream);
+                         const float* gres, float* dx, float* dgamma, float* dbeta, int M, void* gdrop, float drop_p,
+                         unsigned int drop_seed, void* stream);
 
 /* patch_embed / patch_unembed weight gradients on the plain token grid: out fp32 [128][4096] += P^T patches(map);
  * P fp32 [B*T][128], map NHWC bf16 [B][H][W][64], column (i*8+j)*64 + c. */

@@ -229,6 +229,11 @@ def test_layernorm_bwd(dev):
     close(dx, x.grad + gres, 2e-5, 1e-4, "ln dx")
     close(dg, gm.grad, 2e-4, 1e-4, "ln dgamma")
     close(db, bt.grad, 2e-4, 1e-4, "ln dbeta")
+    # the fused form also writes dx through the next Dropout's mask (what tup_dropout_bwd makes of dx): identical bits
+    dx2, dg2, db2, gd = ops.layernorm_bwd(gy.to(torch.bfloat16).to(dev), x.detach().to(dev), mean, rstd, gm.detach().to(dev), gres.to(dev),
+                                          drop=(0.1, 4242))
+    assert torch.equal(dx2, dx) and torch.equal(gd, ops.dropout_bwd(dx, 0.1, 4242))
+    assert (gd == 0).float().mean().item() > 0.05          # the mask drops ~10 %
 
 
 def test_window_attention_bwd(dev, det_sd):

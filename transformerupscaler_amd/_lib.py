@@ -44,7 +44,7 @@ SIGNATURES = {
     "tup_rt_attention_fwd": [P, P, P, I, I, F, U, P],
     "tup_rt_attention_bwd": [P, P, P, P, P, P, I, I, F, U, P],
     "tup_layernorm128_fwd": [P, P, P, P, P, P, I, P],
-    "tup_layernorm128_bwd": [P, P, P, P, P, P, P, P, P, I, P],
+    "tup_layernorm128_bwd": [P, P, P, P, P, P, P, P, P, I, P, F, U, P],
     "tup_rt_patch_wgrad": [P, P, P, I, I, I, P],
     "tup_conv3x3_c64_wgrad_s2d": [P, P, P, P, I, I, I, I, I, P],
     "tup_rt_bicubic_bwd": [P] * 10 + [I, I, I, I, I, P],
@@ -78,7 +78,7 @@ SIGNATURES = {
     "tup_gemm_wgrad_bias": [P, I, I, P, I, I, P, I, P, I, I, I, P],
     "tup_patch_wgrad": [P, P, P, I, I, I, I, P],
     "tup_colsum": [P, I, I, P, I, I, P, P],
-    "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P],
+    "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P, F, U, P],
     "tup_relpos_bias_expand_n": [P, P, P],
     "tup_window_attn_bwd": [P, P, P, P, P, P, P, P, I, F, U, P],
     "tup_window_attn_bwd_scratch": [I, I],
@@ -134,7 +134,13 @@ def load():
     return lib
 
 
+_fns = {}
+
+
 def call(name: str, *args):
-    err = getattr(load(), name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    err = fn(*args)
     if err != 0:
         raise RuntimeError(f"{name} failed with hipError_t {err}")

@@ -96,9 +96,15 @@ def backward_train(pk, sv, gout, reducer=None, l1_scale=None) -> Dict[str, torch
     ready("patch_unembed.weight", "patch_unembed.bias")
     # ---- transformer blocks (reverse) ----
     drop_p, seed = sv["drop_p"], sv["seed"]
+    g_xd = None
     for i in reversed(range(pk["nblocks"])):
         s, p = sv["blocks"][i], f"transformer_blocks.{i}"
-        g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
+        # gradient entering mlp.2's output: through the MLP dropout mask (the residual path keeps g_x itself); from the second
+        # block of the loop on the previous LayerNorm1 backward has written it already (fused dropout_bwd)
+        if g_xd is not None:
+            g_o, g_xd = g_xd, None
+        else:
+            g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
         g[p + ".mlp.2.weight"], g[p + ".mlp.2.bias"] = ops.gemm_wgrad_bias(g_o, s["hid"])
         g_h = ops.gemm_tokens(g_o, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
         del g_o
@@ -114,8 +120,12 @@ def backward_train(pk, sv, gout, reducer=None, l1_scale=None) -> Dict[str, torch
         g[p + ".attn.in_proj_weight"], g[p + ".attn.in_proj_bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.in.wd"], None, "bf16")
         del g_qkv, g_att
-        g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm128_bwd(
-            g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm)
+        if drop_p > 0 and i > 0:          # + the MLP dropout's backward for the block below
+            g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"], g_xd = ops.layernorm128_bwd(
+                g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm, drop=(drop_p, site_seed(seed, i - 1, 2)))
+        else:
+            g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm128_bwd(
+                g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm)
         ready(*[p + sfx for sfx in (".mlp.2.bias", ".mlp.2.weight", ".mlp.0.bias", ".mlp.0.weight", ".norm2.weight",
                                     ".norm2.bias", ".attn.out_proj.bias", ".attn.out_proj.weight", ".attn.in_proj_bias",
                                     ".attn.in_proj_weight", ".norm1.weight", ".norm1.bias")])

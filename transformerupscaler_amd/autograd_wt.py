@@ -88,18 +88,28 @@ def backward_train(pk, frags_t, frags_n, sv, gout, reducer=None) -> Dict[str, to
     ready("patch_unembed.weight", "patch_unembed.bias")
     # ---- window blocks (reverse) ----
     drop_p, seed = sv["drop_p"], sv["seed"]
+    g_xd = None
     for i in reversed(range(pk["nblocks"])):
         s, p = sv["blocks"][i], f"window_blocks.{i}"
-        g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
+        # gradient entering mlp.2's output: through the MLP dropout mask (the residual path keeps g_x itself); from the second
+        # block of the loop on the previous LayerNorm1 backward has written it already (fused dropout_bwd)
+        if g_xd is not None:
+            g_o, g_xd = g_xd, None
+        else:
+            g_o = ops.dropout_bwd(g_x, drop_p, site_seed(seed, i, 2)) if drop_p > 0 else g_x
         g[p + ".mlp.2.weight"], g[p + ".mlp.2.bias"] = ops.gemm_wgrad_bias(g_o, s["hid"])
         g_h = ops.gemm_tokens(g_o, pk[f"b{i}.fc2.wd"], None, "gelu_bwd", aux=s["hpre"])
         del g_o
         g[p + ".mlp.0.weight"], g[p + ".mlp.0.bias"] = ops.gemm_wgrad_bias(g_h, s["y2"])
         g_y2 = ops.gemm_tokens(g_h, pk[f"b{i}.fc1.wd"], None, "bf16")
         del g_h
-        g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"] = ops.layernorm128_bwd(
-            g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
-        g_o = ops.dropout_bwd(g_xm, drop_p, site_seed(seed, i, 1)) if drop_p > 0 else g_xm
+        if drop_p > 0:          # + proj_drop's backward of the result (bf16), in the same pass
+            g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"], g_o = ops.layernorm128_bwd(
+                g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x, drop=(drop_p, site_seed(seed, i, 1)))
+        else:
+            g_xm, g[p + ".norm2.weight"], g[p + ".norm2.bias"] = ops.layernorm128_bwd(
+                g_y2, s["x_mid"], s["mean2"], s["rstd2"], pk[f"b{i}.norm2.w"], gres=g_x)
+            g_o = g_xm
         g[p + ".attn.proj.weight"], g[p + ".attn.proj.bias"] = ops.gemm_wgrad_bias(g_o, s["att"])
         g_att = ops.gemm_tokens(g_o, pk[f"b{i}.proj.wd"], None, "bf16")
         del g_o
@@ -108,8 +118,12 @@ def backward_train(pk, frags_t, frags_n, sv, gout, reducer=None) -> Dict[str, to
         g[p + ".attn.qkv.weight"], g[p + ".attn.qkv.bias"] = ops.gemm_wgrad_bias(g_qkv, s["y1"])
         g_y1 = ops.gemm_tokens(g_qkv, pk[f"b{i}.qkv.wd"], None, "bf16")
         del g_qkv, g_att
-        g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm128_bwd(
-            g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm)
+        if drop_p > 0 and i > 0:          # + the MLP dropout's backward for the block below
+            g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"], g_xd = ops.layernorm128_bwd(
+                g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm, drop=(drop_p, site_seed(seed, i - 1, 2)))
+        else:
+            g_x, g[p + ".norm1.weight"], g[p + ".norm1.bias"] = ops.layernorm128_bwd(
+                g_y1, s["x_in"], s["mean1"], s["rstd1"], pk[f"b{i}.norm1.w"], gres=g_xm)
         ready(*[p + sfx for sfx in (".mlp.2.bias", ".mlp.2.weight", ".mlp.0.bias", ".mlp.0.weight", ".norm2.weight",
                                     ".norm2.bias", ".attn.proj.bias", ".attn.proj.weight",
                                     ".attn.relative_position_bias_table", ".attn.qkv.bias", ".attn.qkv.weight",

@@ -30,7 +30,8 @@ template <int NQ>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const bf16_t* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ gres,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M)
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int M,
+    bf16_t* __restrict__ gdrop, uint32_t drop_thresh, float drop_inv_keep, uint32_t drop_seed)
 {
     constexpr int LD = NQ * 64;              // 192 (FastTransformer) or 128 (ResidualTransformer)
     const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
@@ -87,6 +88,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] += rq[q][e];
                 *reinterpret_cast<f32x4*>(dx + (size_t)row * LD + c) = o;
+                if (gdrop) {       // the gradient's next stop is the Dropout behind the previous Linear (model.py:82,132,150): dx * mask / keep
+                    const uint32_t e0 = (uint32_t)row * LD + c;
+                    *reinterpret_cast<u32x2*>(gdrop + (size_t)row * LD + c) = u32x2{
+                        pack_bf16x2(o[0] * drop_scale(drop_seed, e0, drop_thresh, drop_inv_keep), o[1] * drop_scale(drop_seed, e0 + 1, drop_thresh, drop_inv_keep)),
+                        pack_bf16x2(o[2] * drop_scale(drop_seed, e0 + 2, drop_thresh, drop_inv_keep), o[3] * drop_scale(drop_seed, e0 + 3, drop_thresh, drop_inv_keep))};
+                }
             }
         }
     }
@@ -385,15 +392,19 @@ int ln_bwd_blocks(int M)
 }
 }  // namespace
 
-// dx = LN'(gy) [+ gres]; dgamma/dbeta (fp32 [192]) are accumulated (caller zeroes them).
+// dx = LN'(gy) [+ gres]; dgamma/dbeta (fp32 [192]) are accumulated (caller zeroes them).  gdrop (optional, bf16 [M][192]) also
+// receives dx * dropout mask / (1 - drop_p) for the site keyed by drop_seed (= tup_dropout_bwd of dx, which every LayerNorm backward
+// of a block is followed by: the gradient enters the Dropout behind attn.proj / mlp.2 next, model.py:82,132,150).
 extern "C" int tup_layernorm_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
                                  const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
-                                 int M, void* stream)
+                                 int M, void* gdrop, float drop_p, unsigned int drop_seed, void* stream)
 {
     if (M <= 0) return 0;
+    if (gdrop && (drop_p <= 0.f || drop_p >= 1.f)) return (int)hipErrorInvalidValue;
     const int blocks = ln_bwd_blocks(M);
     layernorm_bwd_kernel<3><<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
+        (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M, (bf16_t*)gdrop,
+        gdrop ? (uint32_t)((double)drop_p * 4294967296.0) : 0u, gdrop ? 1.0f / (1.0f - drop_p) : 1.f, drop_seed);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -401,12 +412,14 @@ extern "C" int tup_layernorm_bwd(const void* gy, const float* x, const float* me
 // Same for the 128-wide rows of ResidualTransformer (model.py:17-18,28,31 of that plugin).
 extern "C" int tup_layernorm128_bwd(const void* gy, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, const float* gres, float* dx, float* dgamma, float* dbeta,
-                                    int M, void* stream)
+                                    int M, void* gdrop, float drop_p, unsigned int drop_seed, void* stream)
 {
     if (M <= 0) return 0;
+    if (gdrop && (drop_p <= 0.f || drop_p >= 1.f)) return (int)hipErrorInvalidValue;
     const int blocks = ln_bwd_blocks(M);
     layernorm_bwd_kernel<2><<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M);
+        (const bf16_t*)gy, x, mean, rstd, gamma, gres, dx, dgamma, dbeta, M, (bf16_t*)gdrop,
+        gdrop ? (uint32_t)((double)drop_p * 4294967296.0) : 0u, gdrop ? 1.0f / (1.0f - drop_p) : 1.f, drop_seed);
     TUP_CHECK_LAUNCH();
     return 0;
 }

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(
     const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ ymin,
     const int* __restrict__ ysize, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
     const int* __restrict__ xsize, const float* __restrict__ xw, int KX, int Hi, int Wi, int Ho, int Wo,
-    int clamp01)
+    int clamp01, size_t both_off)
 {
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(
             acc = fmaf(yw[oy * KY + i], h, acc);
         }
     }
-    if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+    if (clamp01 == 2) out[both_off + ((size_t)plane * Ho + oy) * Wo + ox] = fminf(fmaxf(acc, 0.f), 1.f);
+    else if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
     out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
 }
 
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void resize_aa_sep_kernel(
     const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ ymin,
     const int* __restrict__ ysize, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
     const int* __restrict__ xsize, const float* __restrict__ xw, int KX, int Hi, int Wi, int Ho, int Wo,
-    int clamp01)
+    int clamp01, size_t both_off)
 {
     __shared__ float hbuf[RS_MAXR][256];
     const int col = threadIdx.x;
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(256) void resize_aa_sep_kernel(
         const int y0 = ymin[oy] - r0, ny = ysize[oy];
         float acc = 0.f;
         for (int i = 0; i < ny; ++i) acc = fmaf(yw[oy * KY + i], hbuf[y0 + i][col], acc);
-        if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
+        if (clamp01 == 2) out[both_off + ((size_t)plane * Ho + oy) * Wo + ox] = fminf(fmaxf(acc, 0.f), 1.f);
+        else if (clamp01) acc = fminf(fmaxf(acc, 0.f), 1.f);
         out[((size_t)plane * Ho + oy) * Wo + ox] = acc;
     }
 }
@@ -537,13 +539,13 @@ extern "C" int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, c
     static const bool gather = getenv("TUP_RESIZE_GATHER") != nullptr;             // A/B switch
     if (!gather && KX <= 8 && (long long)RS_TR * Hi / Ho + KY + 2 <= RS_MAXR) {
         resize_aa_sep_kernel<<<dim3((Wo + 255) / 256, (Ho + RS_TR - 1) / RS_TR, planes), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-            in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01);
+            in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01, (size_t)planes * Ho * Wo);
         TUP_CHECK_LAUNCH();
         return 0;
     }
     dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, planes);
     resize_aa_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01);
+        in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01, (size_t)planes * Ho * Wo);
     TUP_CHECK_LAUNCH();
     return 0;
 }

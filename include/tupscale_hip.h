@@ -259,13 +259,19 @@ int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float* dw, float*
 int tup_conv3x3_planar_dgrad(const float* gpl, const float* w, float* gx, int B, int H, int W, int r, void* stream);
 
 /* Backward of Resize(antialias) [+ clamp]: gin fp32 [planes][Hi][Wi]; pre = pre-clamp output or NULL;
- * oy0/oyn/ox0/oxn: per input row/col the range of outputs that reference it. */
+ * oy0/oyn/ox0/oxn: per input row/col the range of outputs that reference it.
+ * l1_scale: NULL, or device float[2] = {d loss / numel, plain} -- then `gout` is the TARGET of nn.L1Loss (train.py:103,132) and the
+ * gradient is formed in the kernel (pre required): plain = 0: sign(clamp(pre) - target) * l1_scale[0], gated by the clamp (pre = the
+ * pre-clamp output); plain != 0: sign(pre - target) * l1_scale[0] with pre = the Resize output itself (train.py:127-130 resizes the
+ * clamped model output, nothing clamps after it).  The loss's backward pass and its 100 MB gradient tensor do not exist. */
 int tup_resize_aa_bwd(const float* gout, const float* pre, float* gin, const int* ymin, const float* yw, int KY,
                       const int* xmin, const float* xw, int KX, const int* oy0, const int* oyn,
-                      const int* ox0, const int* oxn, int planes, int Hi, int Wi, int Ho, int Wo, void* stream);
+                      const int* ox0, const int* oxn, int planes, int Hi, int Wi, int Ho, int Wo,
+                      const float* l1_scale, void* stream);
 
-/* gin = gout * [0 <= pre <= 1] * [relu_src > 0] (clamp / ReLU backward; either source may be NULL). */
-int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, float* gin, long long n, void* stream);
+/* gin = gout * [0 <= pre <= 1] * [relu_src > 0] (clamp / ReLU backward; either source may be NULL); l1_scale as above. */
+int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, float* gin, long long n,
+                 const float* l1_scale, void* stream);
 
 /* Gradient merge at `feat` (model.py:264,268,308 fan-out) + conv2's ReLU backward:
  * out = (a + b + fold_reflect(gpe)) * (feat > 0), NHWC bf16; gpe = padded map from tup_patch_embed_bwd. */

@@ -1,14 +1,14 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r3x; rm -rf $O; mkdir -p $O
+O=gpurun_out/r3z; rm -rf $O; mkdir -p $O
 timeout -k 10 900 python3 -m pytest tests -m gpu -q -s > $O/tests.log 2>&1 || (grep -n "^FAILED\|^E " $O/tests.log | head -30; echo TESTS FAILED)
 tail -2 $O/tests.log
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 - <<'PY'
 import json
-d=json.loads(open('gpurun_out/r3x/bench.json').read().strip().splitlines()[-1])
+d=json.loads(open('gpurun_out/r3z/bench.json').read().strip().splitlines()[-1])
 print('infer', d['value'], d['ms_per_step']); r=d['roofline']; print('roof', r['frac'], r['ms_per_launch'], r['kernel'][:30])
-print('train', d['train']['value'], d['train']['ms_per_step'], 'host', d['train']['host_issue_ms_per_step']); print('rt', d['rt_train']['value'], d['rt_train']['ms_per_step'], 'host', d['rt_train']['host_issue_ms_per_step']); print('x4', d['x4']['value'], d['x4']['ms_per_step'])
+print('train', d['train']['value'], d['train']['ms_per_step']); print('rt', d['rt_train']['value'], d['rt_train']['ms_per_step']); print('x4', d['x4']['value'], d['x4']['ms_per_step'])
 PY
 echo all done

@@ -243,3 +243,34 @@ def test_fused_l1_is_not_used_when_the_output_gradient_is_observed():
     for k, v in _grads(m).items():
         rel = (v - g_plain[k]).norm().item() / max(g_plain[k].norm().item(), 1e-20)
         assert rel <= 1e-3, (k, rel)
+
+
+# ---------------------------------------------------------------- fused L1 in the FastTransformer training step -----------
+@pytest.mark.parametrize("path", ["harness_resize", "model_resize", "no_resize"])
+def test_fast_transformer_fused_l1_equals_materialised_gradient(path, det_sd):
+    """autograd.l1_loss(..., fuse_into_model_backward=True) for the FastTransformer step (train.py:124-138): the loss gradient is formed
+    inside the first backward kernel -- of the Resize of train.py:127-130 (`harness_resize`: model output 96 x 144 squashed to 72 x 108),
+    of the model's own Resize + clamp (`model_resize`, require_ratio=True) or of its clamp (`no_resize`) -- and every parameter
+    gradient equals the one computed from the materialised sign(out - target) / numel."""
+    from transformerupscaler_amd.autograd import l1_loss, resize_aa
+    g = torch.Generator().manual_seed(77)
+    lr_b = torch.rand((2, 3, 48, 72), generator=g).cuda()
+    hw = (96, 144) if path == "no_resize" else (72, 108)
+    hr_b = torch.rand((2, 3) + hw, generator=g).cuda()
+    res = {}
+    for fuse in (False, True):
+        m = _ft(det_sd)
+        if path == "harness_resize":
+            out = resize_aa(m(lr_b, res_out=hw, require_ratio=False), hw)
+        elif path == "model_resize":
+            out = m(lr_b, res_out=hw, require_ratio=True)
+        else:
+            out = m(lr_b, upscale_factor=2)
+        assert tuple(out.shape[2:]) == hw
+        loss = l1_loss(out, hr_b, fuse_into_model_backward=fuse)
+        loss.backward()
+        res[fuse] = (float(loss), _grads(m))
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    worst = max((((res[True][1][k] - v).norm() / v.norm().clamp_min(1e-20)).item(), k) for k, v in res[False][1].items())
+    print("fused vs materialised L1 gradient, worst relative L2:", worst)
+    assert worst[0] <= 1e-3, worst          # same arithmetic; what differs is the order of the weight-gradient kernels' fp32 atomics

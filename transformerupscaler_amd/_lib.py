@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 P = c_void_p
 I = c_int
@@ -91,8 +91,8 @@ SIGNATURES = {
     "tup_conv3x3_c3_wgrad": [P, P, P, P, I, I, I, P],
     "tup_conv3x3_planar_wgrad": [P, P, P, P, I, I, I, I, P],
     "tup_conv3x3_planar_dgrad": [P, P, P, I, I, I, I, P],
-    "tup_resize_aa_bwd": [P, P, P, P, P, I, P, P, I, P, P, P, P, I, I, I, I, I, P],
-    "tup_mask_bwd": [P, P, P, P, c_longlong, P],
+    "tup_resize_aa_bwd": [P, P, P, P, P, I, P, P, I, P, P, P, P, I, I, I, I, I, P, P],
+    "tup_mask_bwd": [P, P, P, P, c_longlong, P, P],
     "tup_feat_grad_combine": [P, P, P, P, P, I, I, I, P],
 }
 

@@ -100,7 +100,7 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, see
     return out, sv
 
 
-def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_input_grad=False) -> Dict[str, torch.Tensor]:
+def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_input_grad=False, l1_scale=None) -> Dict[str, torch.Tensor]:
     """Returns {reference parameter name: gradient} for the parameters active at `scale` (+ "__input__" = d loss / d x when
     `want_input_grad`: conv1's input gradient as a 64 -> 3 conv of the flipped weights)."""
     g: Dict[str, torch.Tensor] = {}
@@ -112,12 +112,12 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
     x, feat, ui = sv["x"], sv["feat"], sv["ui"]
     B, _, H, W = x.shape
     stages = upsampler_layout(scale)
-    gout = gout.contiguous().float()
+    gout = gout.contiguous().float()          # (l1_scale given: the L1 target -- the loss gradient is formed inside the first kernel)
     # ---- clamp (+ resize) ----
     if sv["resized_from"] is not None:
-        g_sum = ops.resize_aa_bwd(gout, sv["resized_from"], pre=sv["pre"])
+        g_sum = ops.resize_aa_bwd(gout, sv["resized_from"], pre=sv["pre"], l1_scale=l1_scale)
     else:
-        g_sum = ops.mask_bwd(gout, pre=sv["pre"])
+        g_sum = ops.mask_bwd(gout, pre=sv["pre"], l1_scale=l1_scale)
     # ---- final_upscale_conv (3->3) + "+ upscaled_input" ----
     ts = sv["ts"]
     g["final_upscale_conv.weight"], g["final_upscale_conv.bias"] = ops.conv_planar_wgrad(ts[-1], g_sum, 1)
@@ -232,6 +232,8 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
 
 
 class _FastTransformerFn(torch.autograd.Function):
+    accepts_fused_l1 = True          # l1_loss may hand (target, scale) to this node instead of a gradient tensor (see _L1LossFn)
+
     @staticmethod
     def forward(ctx, module, x, scale, res_out, require_ratio, names, *params):
         pk, frags_t, frags_n = module.packed(scale, backward=True)
@@ -244,13 +246,23 @@ class _FastTransformerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
+        # the fused-L1 hand-off is validated BEFORE the reducer opens its episode: a refusal here must not leave it open
+        fused = getattr(ctx, "_fused_l1", None)
+        l1_scale = None
+        if fused is not None:
+            target, l1_scale, stand_in = fused
+            ctx._fused_l1 = None
+            if gout.data_ptr() != stand_in.data_ptr() or any(st != 0 for st in gout.stride()):
+                raise RuntimeError("l1_loss(..., fuse_into_model_backward=True): the model output has a consumer besides the loss "
+                                   "(its gradient is not the loss's stand-in); call l1_loss without the fusion")
+            gout = target
         reducer = getattr(ctx.module, "_grad_reducer", None)
         if reducer is not None:
             reducer.begin(ctx.names)          # raises if this step's parameters are not in the reducer's layout
         ops.zero_pool_begin(gout.device)
         try:
             grads = backward_train(ctx.pk, ctx.frags[0], ctx.frags[1], ctx.sv, ctx.scale, gout, reducer,
-                                   want_input_grad=bool(ctx.needs_input_grad[1]))
+                                   want_input_grad=bool(ctx.needs_input_grad[1]), l1_scale=l1_scale)
         except BaseException:
             if reducer is not None:
                 reducer._abort()
@@ -278,14 +290,27 @@ def fast_transformer_function(module, x, scale, res_out, require_ratio):
 
 class _ResizeAAFn(torch.autograd.Function):
     """transforms.Resize on a tensor (train.py:127-130) with a HIP forward and backward."""
+    accepts_fused_l1 = True          # the loss of train.py:132 sits right behind this Resize: its gradient is formed inside the backward kernel
 
     @staticmethod
     def forward(ctx, x, size):
         ctx.in_hw = tuple(x.shape[2:])
-        return ops.resize_aa(x.contiguous().float(), tuple(size), clamp=False)
+        out = ops.resize_aa(x.contiguous().float(), tuple(size), clamp=False)
+        ctx.save_for_backward(out)          # only read when the L1 loss hands its target over (sign(out - target))
+        return out
 
     @staticmethod
     def backward(ctx, gout):
+        fused = getattr(ctx, "_fused_l1", None)
+        if fused is not None:
+            out, = ctx.saved_tensors
+            target, scale, stand_in = fused
+            ctx._fused_l1 = None
+            if gout.data_ptr() != stand_in.data_ptr() or any(st != 0 for st in gout.stride()):
+                raise RuntimeError("l1_loss(..., fuse_into_model_backward=True): the resized output has a consumer besides the loss "
+                                   "(its gradient is not the loss's stand-in); call l1_loss without the fusion")
+            scale[1] = 1.0          # plain: `pre` below is the loss input itself, no clamp between this Resize and the loss
+            return ops.resize_aa_bwd(target, ctx.in_hw, pre=out, l1_scale=scale), None
         return ops.resize_aa_bwd(gout.contiguous().float(), ctx.in_hw), None
 
 
@@ -313,8 +338,10 @@ class _L1LossFn(torch.autograd.Function):
         if ctx.model_node is not None:
             # hand (target, d loss / numel) to the model's backward node, which forms sign(out - target) * scale inside its first
             # kernel; what is returned here is a stride-0 stand-in of the right shape that node recognises and never reads
-            scale = (g.detach().float().reshape(1) / out.numel()).contiguous()
-            stand_in = scale.expand(out.shape)
+            # scale = {d loss / numel, 0}: the second float is the receiving node's "plain" flag (csrc/conv_bwd.hip l1_grad_plain)
+            scale = torch.zeros(2, dtype=torch.float32, device=out.device)
+            scale[:1] = g.detach().float().reshape(1) / out.numel()
+            stand_in = scale[:1].expand(out.shape)
             ctx.model_node._fused_l1 = (target, scale, stand_in)
             return stand_in, None, None
         return ops.l1_loss_bwd(out, target, g.contiguous().float().reshape(1)), None, None
@@ -322,7 +349,7 @@ class _L1LossFn(torch.autograd.Function):
 
 def l1_loss(out: torch.Tensor, target: torch.Tensor, fuse_into_model_backward: bool = False) -> torch.Tensor:
     """nn.L1Loss()(out, target).  fuse_into_model_backward=True (the training harness, where the model output feeds the loss and
-    nothing else, train.py:124-136): when `out` comes straight from a model whose backward supports it (ResidualTransformer), the
+    nothing else, train.py:124-136): when `out` comes straight from a model whose backward supports it (FastTransformer, ResidualTransformer), the
     loss gradient is not materialised -- the model's first backward kernel computes sign(out - target) / numel itself.  The model's
     backward raises if it then receives anything but that stand-in (an output with a second consumer).  Under the fusion the
     gradient that flows into `out` is that stand-in, not sign(out - target) / numel: ``out.grad`` / tensor hooks on `out` would

@@ -78,7 +78,7 @@ def backward_train(pk, sv, gout, reducer=None, l1_scale=None) -> Dict[str, torch
     # ---- clamp + bicubic (only the residual branch carries parameters); l1_scale: gout is the target of an L1 loss on the
     #      output and the loss gradient is formed inside the kernel (autograd.l1_loss(..., fuse_into_model_backward=True)) ----
     gout = gout.contiguous().float()
-    g_res = ops.rt_bicubic_bwd(gout, sv["out"], (hd, wd), l1_scale=l1_scale)
+    g_res = ops.rt_bicubic_bwd(gout, sv["out"], (hd, wd), l1_scale=None if l1_scale is None else l1_scale[:1])
     # ---- decoder_conv2 (64->3), decoder_conv1's ReLU, decoder_conv1 ----
     dwp, db = ops.conv_thin_wgrad(sv["dec"], g_res, True)
     g["decoder_conv2.weight"], g["decoder_conv2.bias"] = dwp.permute(0, 2, 1).reshape(3, 64, 3, 3), db

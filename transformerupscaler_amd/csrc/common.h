@@ -194,7 +194,10 @@ TUP_DEVICE void gelu16_fragments(const f32x4 (&acc1)[2][2], bf16x8 (&hfr)[2]) {
             hv[tg * 4 + hh * 2 + 0] = __builtin_convertvector(f32x2{acc1[tg][hh][0], acc1[tg][hh][1]}, h2);
             hv[tg * 4 + hh * 2 + 1] = __builtin_convertvector(f32x2{acc1[tg][hh][2], acc1[tg][hh][3]}, h2);
         }
+#ifndef TUP_EXP_NOGELU          // timing experiment (wrong results): the whole-block kernel without the GELU arithmetic = the most that
+                                // hiding it behind the fc1 / fc2 MFMAs could gain
     gelu16_batch<8>(hv);
+#endif
 #pragma unroll
     for (int tg = 0; tg < 2; ++tg) {
         u32x4 pk;

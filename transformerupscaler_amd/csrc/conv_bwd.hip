@@ -611,6 +611,18 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_planar_r2x4_kernel(
     for (int ci = 0; ci < 3; ++ci) *reinterpret_cast<f32x4*>(gx + o + (size_t)ci * H * W) = acc[ci];
 }
 
+// Fused L1 loss (autograd.l1_loss(..., fuse_into_model_backward=True)): the gradient that enters the clamp is not read from memory but
+// formed here, sign(clamp(pre) - target) * scale with scale = d loss / numel on the device (nn.L1Loss backward, train.py:132,138).
+TUP_DEVICE float l1_grad(float pre, float target, float s) {
+    const float d = fminf(fmaxf(pre, 0.f), 1.f) - target;
+    return d > 0.f ? s : (d < 0.f ? -s : 0.f);
+}
+// l1_scale[1] != 0 ("plain"): `pre` is the loss input itself (the Resize output of train.py:127-130, nothing clamps it): no clamp, no gate
+TUP_DEVICE float l1_grad_plain(float o, float target, float s) {
+    const float d = o - target;
+    return d > 0.f ? s : (d < 0.f ? -s : 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward of (antialiased resize -> clamp): gin[y][x] = sum over the output pixels whose taps cover
 // (y, x) of wy*wx*gout, gout masked by 0 <= pre <= 1 when `pre` (the pre-clamp output) is given.
@@ -620,8 +632,10 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ pre, float* __restrict__ gin,
     const int* __restrict__ ymin, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
     const float* __restrict__ xw, int KX, const int* __restrict__ oy0, const int* __restrict__ oyn,
-    const int* __restrict__ ox0, const int* __restrict__ oxn, int Hi, int Wi, int Ho, int Wo)
+    const int* __restrict__ ox0, const int* __restrict__ oxn, int Hi, int Wi, int Ho, int Wo, const float* __restrict__ l1_scale)
 {
+    const float l1s = l1_scale ? l1_scale[0] : 0.f;          // fused L1: `gout` is the loss target
+    const bool plain = l1_scale && l1_scale[1] != 0.f;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int plane = blockIdx.z;
@@ -643,7 +657,11 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_kernel(
             for (int j = 0; j < 4; ++j) {
                 const size_t o = (size_t)oy * Wo + min(xa + j, Wo - 1);
                 gv[j] = j < xn ? go[o] : 0.f;
-                if (pr) { const float pv = pr[o]; if (!(pv >= 0.f && pv <= 1.f)) gv[j] = 0.f; }
+                if (pr) {
+                    const float pv = pr[o];
+                    if (l1_scale) gv[j] = plain ? l1_grad_plain(pv, gv[j], l1s) : l1_grad(pv, gv[j], l1s);
+                    if ((!plain && !(pv >= 0.f && pv <= 1.f)) || j >= xn) gv[j] = 0.f;
+                }
             }
             float h = 0.f;
 #pragma unroll
@@ -658,7 +676,11 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_kernel(
             for (int j = 0; j < xn; ++j) {
                 const int ox = xa + j;
                 float gv = go[(size_t)oy * Wo + ox];
-                if (pr) { const float pv = pr[(size_t)oy * Wo + ox]; if (!(pv >= 0.f && pv <= 1.f)) gv = 0.f; }
+                if (pr) {
+                    const float pv = pr[(size_t)oy * Wo + ox];
+                    if (l1_scale) gv = plain ? l1_grad_plain(pv, gv, l1s) : l1_grad(pv, gv, l1s);
+                    if (!plain && !(pv >= 0.f && pv <= 1.f)) gv = 0.f;
+                }
                 h = fmaf(xw[ox * KX + (x - xmin[ox])], gv, h);
             }
             acc = fmaf(wyv, h, acc);
@@ -675,9 +697,11 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_sep_kernel(
     const float* __restrict__ gout, const float* __restrict__ pre, float* __restrict__ gin,
     const int* __restrict__ ymin, const float* __restrict__ yw, int KY, const int* __restrict__ xmin,
     const float* __restrict__ xw, int KX, const int* __restrict__ oy0, const int* __restrict__ oyn,
-    const int* __restrict__ ox0, const int* __restrict__ oxn, int Hi, int Wi, int Ho, int Wo)
+    const int* __restrict__ ox0, const int* __restrict__ oxn, int Hi, int Wi, int Ho, int Wo, const float* __restrict__ l1_scale)
 {
     __shared__ float tbuf[RB_MAXR][256];
+    const float l1s = l1_scale ? l1_scale[0] : 0.f;          // fused L1: `gout` is the loss target
+    const bool plain = l1_scale && l1_scale[1] != 0.f;
     const int col = threadIdx.x;
     const int x = blockIdx.x * 256 + col, xc = min(x, Wi - 1);
     const int ya = blockIdx.y * RB_TR, yb = min(ya + RB_TR, Hi) - 1;
@@ -709,7 +733,10 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_sep_kernel(
         for (int u = 0; u < 4; ++u) {
             float h = 0.f;
 #pragma unroll
-            for (int j = 0; j < XN; ++j) h = fmaf(wx[j], (pv[u][j] >= 0.f && pv[u][j] <= 1.f) ? gv[u][j] : 0.f, h);
+            for (int j = 0; j < XN; ++j) {
+                const float gg = !l1_scale ? gv[u][j] : (plain ? l1_grad_plain(pv[u][j], gv[u][j], l1s) : l1_grad(pv[u][j], gv[u][j], l1s));
+                h = fmaf(wx[j], (plain || (pv[u][j] >= 0.f && pv[u][j] <= 1.f)) ? gg : 0.f, h);          // (wx[j] = 0 beyond the column's outputs)
+            }
             if (oy + u <= o1) tbuf[oy + u - o0][col] = h;
         }
     }
@@ -727,13 +754,15 @@ __global__ __launch_bounds__(256) void resize_aa_bwd_sep_kernel(
 
 // gin = gout * (0 <= pre <= 1) [* (relu_src > 0)]
 __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
-                                                       const float* __restrict__ relu_src, float* __restrict__ gin, size_t n)
+                                                       const float* __restrict__ relu_src, float* __restrict__ gin, size_t n,
+                                                       const float* __restrict__ l1_scale)
 {
+    const float l1s = l1_scale ? l1_scale[0] : 0.f;          // fused L1: `gout` is the loss target, `pre` is required
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n; i += stride) {
         float g = gout[i];
-        if (pre) { const float p = pre[i]; if (!(p >= 0.f && p <= 1.f)) g = 0.f; }
+        if (pre) { const float p = pre[i]; if (l1_scale) g = l1_grad(p, g, l1s); if (!(p >= 0.f && p <= 1.f)) g = 0.f; }
         if (relu_src && !(relu_src[i] > 0.f)) g = 0.f;
         gin[i] = g;
     }
@@ -899,33 +928,36 @@ extern "C" int tup_conv3x3_planar_dgrad(const float* gpl, const float* w, float*
 // gin fp32 [planes][Hi][Wi] (overwritten) = backward of resize (+ clamp mask from `pre`, may be NULL).
 extern "C" int tup_resize_aa_bwd(const float* gout, const float* pre, float* gin, const int* ymin, const float* yw, int KY,
                                  const int* xmin, const float* xw, int KX, const int* oy0, const int* oyn,
-                                 const int* ox0, const int* oxn, int planes, int Hi, int Wi, int Ho, int Wo, void* stream)
+                                 const int* ox0, const int* oxn, int planes, int Hi, int Wi, int Ho, int Wo,
+                                 const float* l1_scale, void* stream)
 {
     if (planes <= 0) return 0;
-    if (planes > 65535) return (int)hipErrorInvalidValue;
+    if (planes > 65535 || (l1_scale && !pre)) return (int)hipErrorInvalidValue;
     // separable kernel when a column is referenced by <= 6 outputs (an output reads KX adjacent columns, so an input column feeds at
     // most KX * Wo / Wi + 2 outputs) and RB_TR input rows never reference more than RB_MAXR output rows
     static const bool gather = getenv("TUP_RESIZE_GATHER") != nullptr;             // A/B switch
     if (!gather && (long long)KX * Wo / Wi + 2 <= 6 && (long long)RB_TR * Ho / Hi + KY + 2 <= RB_MAXR) {
         resize_aa_bwd_sep_kernel<<<dim3((Wi + 255) / 256, (Hi + RB_TR - 1) / RB_TR, planes), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-            gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo);
+            gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo, l1_scale);
         TUP_CHECK_LAUNCH();
         return 0;
     }
     dim3 grid((Wi + 63) / 64, (Hi + 3) / 4, planes);
     resize_aa_bwd_kernel<<<grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo);
+        gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo, l1_scale);
     TUP_CHECK_LAUNCH();
     return 0;
 }
 
 // gin = gout * [0 <= pre <= 1] * [relu_src > 0]   (either mask source may be NULL)
-extern "C" int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, float* gin, long long n, void* stream)
+extern "C" int tup_mask_bwd(const float* gout, const float* pre, const float* relu_src, float* gin, long long n,
+                            const float* l1_scale, void* stream)
 {
     if (n <= 0) return 0;
+    if (l1_scale && !pre) return (int)hipErrorInvalidValue;
     long long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    mask_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(gout, pre, relu_src, gin, (size_t)n);
+    mask_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(gout, pre, relu_src, gin, (size_t)n, l1_scale);
     TUP_CHECK_LAUNCH();
     return 0;
 }

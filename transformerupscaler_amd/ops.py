@@ -607,8 +607,10 @@ def _inv_taps_on(device, in_size, out_size):
     return _INV_CACHE[key]
 
 
-def resize_aa_bwd(gout, in_hw, pre=None):
-    """Backward of resize_aa (+clamp when `pre`, the pre-clamp output, is given)."""
+def resize_aa_bwd(gout, in_hw, pre=None, l1_scale=None):
+    """Backward of resize_aa (+clamp when `pre`, the pre-clamp output, is given).  l1_scale (device float[2] = {d loss / numel,
+    plain}): `gout` is the L1 target and the loss gradient is formed inside the kernel (autograd.l1_loss(...,
+    fuse_into_model_backward=True)); plain != 0: `pre` is the loss input itself (this Resize's output), no clamp in between."""
     B, C, Ho, Wo = gout.shape
     Hi, Wi = in_hw
     ylo, _, yw, ky = _taps_on(gout.device, Hi, Ho)
@@ -618,14 +620,14 @@ def resize_aa_bwd(gout, in_hw, pre=None):
     gin = torch.empty((B, C, Hi, Wi), dtype=F32, device=gout.device)
     _lib.call("tup_resize_aa_bwd", _chk(gout, F32, None, "gout"), _opt(pre, F32, gout.shape, "pre"), gin.data_ptr(),
               ylo.data_ptr(), yw.data_ptr(), ky, xlo.data_ptr(), xw.data_ptr(), kx, oy0.data_ptr(), oyn.data_ptr(),
-              ox0.data_ptr(), oxn.data_ptr(), B * C, Hi, Wi, Ho, Wo, _stream())
+              ox0.data_ptr(), oxn.data_ptr(), B * C, Hi, Wi, Ho, Wo, _opt(l1_scale, F32, (2,), "l1_scale"), _stream())
     return gin
 
 
-def mask_bwd(gout, pre=None, relu_src=None):
+def mask_bwd(gout, pre=None, relu_src=None, l1_scale=None):
     gin = torch.empty_like(gout)
     _lib.call("tup_mask_bwd", _chk(gout, F32, None, "gout"), _opt(pre, F32, gout.shape, "pre"),
-              _opt(relu_src, F32, gout.shape, "relu_src"), gin.data_ptr(), gout.numel(), _stream())
+              _opt(relu_src, F32, gout.shape, "relu_src"), gin.data_ptr(), gout.numel(), _opt(l1_scale, F32, (2,), "l1_scale"), _stream())
     return gin
 
 

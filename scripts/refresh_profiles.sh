@@ -36,8 +36,10 @@ else
       timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_${m}_$c -- python3 bench.py --steps 3 --warmup 1 --mode $m --no-cpu-baseline > $O/pmc_${m}_$c.log 2>&1
       echo "pmc $m $c done"
     done
-    python3 scripts/pmc_traffic.py $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE $O/r03_kernel_stats_$m.csv $O/r03_pmc_traffic_$m.json $m
+    # durations: part a's stats of this mode (copied to profiles/ between the two calls: gpurun_out/ does not travel to the box)
+    python3 scripts/pmc_traffic.py $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE profiles/r03_kernel_stats_$m.csv $O/r03_pmc_traffic_$m.json $m
     rm -rf $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE
   done
 fi
+if [ "$part" = b ]; then timeout -k 10 120 python3 scripts/microbench_hbm.py > $O/r03_microbench_hbm.txt 2>&1; cat $O/r03_microbench_hbm.txt; fi
 echo "refresh $part done"

@@ -27,6 +27,15 @@ def keep_mask(seed, n, p):
     return torch.from_numpy((drop_hash(seed, np.arange(n)) >= thresh).astype(np.float32))
 
 
+def keep_mask_pairs(seed, n, p):
+    """Attention-probability masks (csrc/common.h drop_pair*): one hash per PAIR of neighbouring keys, the even key takes the low 16
+    bits, the odd key the high 16 bits; keep iff field >= round(p * 65536).  Returns (mask, 1 / keep probability of the mask)."""
+    t = min(max(int(p * 65536.0 + 0.5), 1), 65535)
+    h = drop_hash(seed, np.arange(n) >> 1)
+    field = np.where((np.arange(n) & 1) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return torch.from_numpy((field >= np.uint64(t)).astype(np.float32)), 65536.0 / (65536.0 - t)
+
+
 def bf(t):
     return t.to(torch.bfloat16).float()
 
@@ -58,8 +67,10 @@ def test_attention_dropout_forward_backward(det_sd):
     idx = O.relative_position_index(8)
     q, k, v = qkv.view(nwin, 64, 3, 12, 16).permute(2, 0, 3, 1, 4)
     attn = ((q * 0.25) @ k.transpose(-2, -1) + table[idx.view(-1)].view(64, 64, 12).permute(2, 0, 1).unsqueeze(0)).softmax(-1)
-    mask = keep_mask(seed, nwin * 12 * 64 * 64, p).view(nwin, 12, 64, 64)       # index ((win*12+h)*64+q)*64+k
-    out = ((attn * mask / (1 - p)) @ v).transpose(1, 2).reshape(nwin * 64, 192)
+    mask, inv_keep = keep_mask_pairs(seed, nwin * 12 * 64 * 64, p)              # index ((win*12+h)*64+q)*64+k
+    mask = mask.view(nwin, 12, 64, 64)
+    assert abs(mask.mean().item() - 0.9) < 0.005 and abs(inv_keep - 1 / 0.9) < 1e-4
+    out = ((attn * mask * inv_keep) @ v).transpose(1, 2).reshape(nwin * 64, 192)
     gout = bf(rnd((nwin * 64, 192), 7))
     out.backward(gout)
     tb = table.detach().cuda()

@@ -103,3 +103,32 @@ def test_rt_attention_backward(B, N):
     ref = qkv.grad.view(B * N, 384)
     err = (gq - ref).abs().max().item()
     assert err <= 2e-2 + 2e-2 * ref.abs().max().item(), err
+
+
+@pytest.mark.parametrize("B,N", [(2, 200), (1, 3600)])
+def test_rt_attention_dropout_forward_backward(B, N):
+    """nn.MultiheadAttention(dropout=0.1) in .train() (models/ResidualTransformer/model.py:21,43): the three attention kernels
+    (forward, dQ, dK/dV) derive the SAME stateless mask -- one hash per pair of neighbouring keys (csrc/common.h drop_pair*, stream
+    seed + (b * 8 + h) * 0x9E3779B9, element q * N + k) -- restated here in numpy: forward and gradient against torch math using it."""
+    from transformerupscaler_amd import ops
+    from test_hip_dropout import keep_mask_pairs
+    p, seed = 0.1, 4711
+    qkv = bf(rnd((B, N, 384), 24, 1.5)).requires_grad_(True)
+    q, k, v = qkv.view(B, N, 3, 8, 16).permute(2, 0, 3, 1, 4)
+    mask = torch.empty((B, 8, N, N))
+    for b in range(B):
+        for h in range(8):
+            m, inv_keep = keep_mask_pairs((seed + (b * 8 + h) * 0x9E3779B9) & 0xFFFFFFFF, N * N, p)
+            mask[b, h] = m.view(N, N)
+    assert abs(mask.mean().item() - 0.9) < 0.005
+    attn = torch.softmax((q * 0.25) @ k.transpose(-2, -1), -1)
+    out = ((attn * mask * inv_keep) @ v).transpose(1, 2).reshape(B * N, 128)
+    gout = bf(rnd((B * N, 128), 25))
+    out.backward(gout)
+    qd = qkv.detach().view(B * N, 384).to(torch.bfloat16).cuda()
+    o, lse = ops.rt_attention(qd, B, N, save_lse=True, drop_p=p, drop_seed=seed)
+    assert (o.float().cpu() - out.detach()).abs().max() <= 2e-2
+    gq = ops.rt_attention_bwd(qd, o, gout.to(torch.bfloat16).cuda(), lse, B, N, drop_p=p, drop_seed=seed).float().cpu()
+    ref = qkv.grad.view(B * N, 384)
+    err = (gq - ref).abs().max().item()
+    assert err <= 2e-2 + 2e-2 * ref.abs().max().item(), err

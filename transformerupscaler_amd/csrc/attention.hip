@@ -163,13 +163,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const int kt = 2 * kp + hh;
-                float pv[4];
+                float pv[4], dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop_thresh) drop_pair4(drop_seed, ((uint32_t)pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g, drop_thresh, drop_inv_keep, dm);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    pv[e] = st[kt][qt][e] * inv[qt];
-                    if (drop_thresh)
-                        pv[e] *= drop_scale(drop_seed, ((uint32_t)pair * 64u + 16u * qt + p) * 64u + 16u * kt + 4u * g + e, drop_thresh, drop_inv_keep);
-                }
+                for (int e = 0; e < 4; ++e) pv[e] = st[kt][qt][e] * inv[qt] * dm[e];
                 pw[2 * hh] = pack_bf16x2(pv[0], pv[1]);
                 pw[2 * hh + 1] = pack_bf16x2(pv[2], pv[3]);
             }
@@ -226,9 +223,10 @@ extern "C" int tup_window_attn_fwd(const void* qkv, const float* bias_frag, void
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
     const int npairs = nwin * 12;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    uint32_t thresh; float inv_keep;
+    drop_pair_params(drop_p, thresh, inv_keep);
     window_attn_kernel<12><<<dim3((npairs + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        (const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        (const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, inv_keep, drop_seed);
     TUP_CHECK_LAUNCH();
     return 0;
 }
@@ -241,13 +239,14 @@ extern "C" int tup_window_attn_fwd_h(const void* qkv, const float* bias_frag, vo
     if (nwin <= 0) return 0;
     if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
     const int npairs = nwin * heads;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    uint32_t thresh; float inv_keep;
+    drop_pair_params(drop_p, thresh, inv_keep);
     const dim3 grid((npairs + 3) / 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (heads == 12)
-        window_attn_kernel<12><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        window_attn_kernel<12><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, inv_keep, drop_seed);
     else if (heads == 8)
-        window_attn_kernel<8><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        window_attn_kernel<8><<<grid, dim3(256), 0, s>>>((const bf16_t*)qkv, bias_frag, (bf16_t*)out, lse, npairs, thresh, inv_keep, drop_seed);
     else return (int)hipErrorInvalidValue;
     TUP_CHECK_LAUNCH();
     return 0;

@@ -286,18 +286,14 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(
                     const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
                     const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
                     f32x4 pr, ds;
+                    float dm[4] = {1.f, 1.f, 1.f, 1.f};          // O = D(P) V with D = mask/keep: dP = mask/keep * (dO V^T)
+                    if (drop_thresh)       // this lane: queries 4g .. 4g+3 of one key; the key's pair partner is the neighbouring lane
+                        drop_pair4_rows(drop_seed, (pair * 64u + 16u * qt + 4u * g) * 64u + 16u * kt + p, 64u, drop_thresh, drop_inv_keep, dm);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         pr[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(__builtin_fmaf(s[e], 0.25f, bf[e]), 1.4426950408889634f, -l2[hh][e]));
-                        float dpe = dp[e];
-                        if (drop_thresh) {     // O = D(P) V with D = mask/keep: dP = mask/keep * (dO V^T)
-                            const float m = drop_scale(drop_seed, (pair * 64u + 16u * qt + 4u * g + e) * 64u + 16u * kt + p, drop_thresh, drop_inv_keep);
-                            dpe *= m;
-                            ds[e] = pr[e] * (dpe - dd[hh][e]);
-                            pr[e] *= m;                    // dV uses the dropped probabilities
-                        } else {
-                            ds[e] = pr[e] * (dpe - dd[hh][e]);
-                        }
+                        ds[e] = pr[e] * (dp[e] * dm[e] - dd[hh][e]);
+                        pr[e] *= dm[e];                    // dV uses the dropped probabilities
                         dbacc[qt][kt][e] += ds[e];
                     }
                     prb[hh] = to_bf16x4(pr);
@@ -462,12 +458,13 @@ int launch_attn_bwd(const void* qkv, const void* gout, const void* att, const fl
                     float* dbias_n, float* scratch, int nwin, float drop_p, unsigned int drop_seed, hipStream_t s)
 {
     if (scratch == nullptr || att == nullptr || lse == nullptr) return (int)hipErrorInvalidValue;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+    uint32_t thresh; float inv_keep;
+    drop_pair_params(drop_p, thresh, inv_keep);
     const int nslots = attn_bwd_slots(nwin, HEADS);
     const int nwaves = nslots * HEADS;            // multiple of 4 because HEADS is
     window_attn_bwd_kernel<HEADS><<<dim3(nwaves / 4), dim3(256), 0, s>>>(
         (const bf16_t*)qkv, (const bf16_t*)gout, (const bf16_t*)att, lse, bias_n, (bf16_t*)gqkv, scratch, nwin, nslots,
-        thresh, 1.0f / (1.0f - drop_p), drop_seed);
+        thresh, inv_keep, drop_seed);
     TUP_CHECK_LAUNCH();
     const int n4 = HEADS * 1024;
     dbias_sum_kernel<<<dim3(n4 / 64), dim3(256), 0, s>>>(scratch, dbias_n, n4, nslots);

@@ -236,6 +236,48 @@ TUP_DEVICE uint32_t drop_hash(uint32_t seed, uint32_t idx) {
 TUP_DEVICE float drop_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
     return drop_hash(seed, idx) >= thresh ? inv_keep : 0.f;
 }
+// Attention-probability masks (attn_drop, model.py:80,127; nn.MultiheadAttention's dropout in the ResidualTransformer): ONE hash
+// decides TWO neighbouring keys.  Element index idx = row * ncols + key with ncols even (64 or 3600): h = drop_hash(seed, idx >> 1);
+// the even key takes the low 16 bits, the odd key the high 16 bits; keep iff field >= thresh16 = round(p * 65536).  The kernels get
+// thresh_hi = thresh16 << 16 (a field compares against it in place) and inv_keep = 65536 / (65536 - thresh16) (the exact keep
+// probability of the mask, so E[mask * inv_keep] = 1).  The hash is three quarter-rate multiplies + five xor / shift per call and was
+// the most expensive thing per score of the attention kernels (1.0 ms of the 9.2 ms ResidualTransformer step): a lane
+// that holds four consecutive keys of a row now pays two of them instead of four.
+TUP_DEVICE float drop_pair_lo(uint32_t h, uint32_t thresh_hi, float inv_keep) { return (h << 16) >= thresh_hi ? inv_keep : 0.f; }
+TUP_DEVICE float drop_pair_hi(uint32_t h, uint32_t thresh_hi, float inv_keep) { return h >= thresh_hi ? inv_keep : 0.f; }
+TUP_DEVICE float drop_pair(uint32_t seed, uint32_t idx, uint32_t thresh_hi, float inv_keep) {      // one element (a lane whose values are not neighbours)
+    const uint32_t h = drop_hash(seed, idx >> 1);
+    return ((idx & 1u) ? h : (h << 16)) >= thresh_hi ? inv_keep : 0.f;
+}
+// four consecutive elements idx0 .. idx0 + 3, idx0 a multiple of 4
+TUP_DEVICE void drop_pair4(uint32_t seed, uint32_t idx0, uint32_t thresh_hi, float inv_keep, float (&m)[4]) {
+    const uint32_t h0 = drop_hash(seed, idx0 >> 1), h1 = drop_hash(seed, (idx0 >> 1) + 1u);
+    m[0] = drop_pair_lo(h0, thresh_hi, inv_keep); m[1] = drop_pair_hi(h0, thresh_hi, inv_keep);
+    m[2] = drop_pair_lo(h1, thresh_hi, inv_keep); m[3] = drop_pair_hi(h1, thresh_hi, inv_keep);
+}
+// four elements of ONE key column, rows r0 .. r0 + 3 (idx0 = r0 * ncols + key; the layout of the backward kernels that keep queries along
+// a lane's values).  The two keys of a hash pair sit in neighbouring lanes (key parity = lane parity: the key tile starts at an even
+// key, ncols is even), so each lane hashes TWO of the four rows and takes the other two from its neighbour (quad_perm DPP): two
+// hashes per four decisions here as well.  All lanes of the wave must be active.
+TUP_DEVICE void drop_pair4_rows(uint32_t seed, uint32_t idx0, uint32_t ncols, uint32_t thresh_hi, float inv_keep, float (&m)[4]) {
+    const bool odd = (idx0 & 1u) != 0u;
+    const uint32_t ia = (idx0 + (odd ? 2u * ncols : 0u)) >> 1;          // even lane: rows 0, 1; odd lane: rows 2, 3
+    const uint32_t ha = drop_hash(seed, ia), hb = drop_hash(seed, ia + (ncols >> 1));
+    const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xf, 0xf, false);      // quad_perm(1,0,3,2): lane ^ 1
+    const uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xf, 0xf, false);
+    const uint32_t h[4] = {odd ? pa : ha, odd ? pb : hb, odd ? ha : pa, odd ? hb : pb};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = (odd ? h[e] : (h[e] << 16)) >= thresh_hi ? inv_keep : 0.f;
+}
+// host side: p -> (thresh_hi, inv_keep)
+inline void drop_pair_params(float p, uint32_t& thresh_hi, float& inv_keep) {
+    if (!(p > 0.f)) { thresh_hi = 0u; inv_keep = 1.f; return; }
+    long t = (long)((double)p * 65536.0 + 0.5);
+    if (t < 1) t = 1;
+    if (t > 65535) t = 65535;
+    thresh_hi = (uint32_t)t << 16;
+    inv_keep = (float)(65536.0 / (65536.0 - (double)t));
+}
 
 // Raises a kernel's dynamic-LDS limit once per DEVICE (the attribute is per device; a process-wide flag would leave
 // every device after the first at the 64 KB default).

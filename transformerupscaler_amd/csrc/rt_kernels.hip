@@ -122,9 +122,12 @@ __global__ __launch_bounds__(256) void rt_attention_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { pv[e] = __builtin_amdgcn_exp2f(st[kt][qt][e] - mx); sum += pv[e]; }
                     if constexpr (DROP) {       // nn.MultiheadAttention drops the normalised probabilities: l keeps the full sum
+                        // four consecutive keys of one query row: two hashes (common.h drop_pair4; N is a multiple of 4, so is qi)
                         const uint32_t qi = (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + 4 * g);
+                        float dm[4];
+                        drop_pair4(hseed, qi, thresh, inv_keep, dm);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pv[e] *= drop_scale(hseed, qi + e, thresh, inv_keep);
+                        for (int e = 0; e < 4; ++e) pv[e] *= dm[e];
                     }
                     pp[hh] = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])});
                 }
@@ -350,12 +353,14 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
                     const f32x4 s = mfma16x16x16(kf[kt], qf[qt], f32x4{0.f, 0.f, 0.f, 0.f});
                     const f32x4 dp = mfma16x16x16(vf[kt], dof[qt], f32x4{0.f, 0.f, 0.f, 0.f});
                     f32x4 ds;
+                    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (DROP) drop_pair4(hseed, (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + 4 * g), thresh, inv_keep, dm);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int key = k0 + 16 * kt + 4 * g + e;
                         const float pr = key < N ? __expf(s[e] * 0.25f - lc[qt]) : 0.f;
                         float dpe = dp[e];
-                        if constexpr (DROP) dpe *= drop_scale(hseed, (uint32_t)(q0 + 16 * qt + p) * (uint32_t)N + (uint32_t)key, thresh, inv_keep);
+                        if constexpr (DROP) dpe *= dm[e];
                         ds[e] = pr * (dpe - dc[qt]);
                     }
                     dsb[hh] = f4_to_bf16x4(ds);
@@ -458,18 +463,15 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
                     const f32x4 s = mfma16x16x16(qf[qt], kf[kt], f32x4{0.f, 0.f, 0.f, 0.f});       // rows query 4g+e, cols key p
                     const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
                     f32x4 pr, ds;
+                    float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (DROP)       // queries 4g .. 4g+3 of one key per lane; the key's pair partner is the neighbouring lane
+                        drop_pair4_rows(hseed, (uint32_t)(q0 + 16 * qt + 4 * g) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + p), (uint32_t)N, thresh, inv_keep, dm);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qq = q0 + 16 * qt + 4 * g + e;
                         pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
-                        float dpe = dp[e];
-                        float keep = 1.0f;
-                        if constexpr (DROP) {
-                            keep = drop_scale(hseed, (uint32_t)qq * (uint32_t)N + (uint32_t)(k0 + 16 * kt + p), thresh, inv_keep);
-                            dpe *= keep;
-                        }
-                        ds[e] = pr[e] * (dpe - dr[qt][e]);
-                        pr[e] *= keep;                       // dV sees the dropped probabilities
+                        ds[e] = pr[e] * (dp[e] * dm[e] - dr[qt][e]);
+                        pr[e] *= dm[e];                      // dV sees the dropped probabilities
                     }
                     prb[hh] = f4_to_bf16x4(pr);
                     dsb[hh] = f4_to_bf16x4(ds);
@@ -718,9 +720,9 @@ __global__ __launch_bounds__(256) void rt_bicubic_bwd_cols_dense_kernel(
 extern "C" int tup_rt_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, float drop_p,
                                     unsigned int drop_seed, void* stream)
 {
-    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    const float inv_keep = 1.0f / (1.0f - drop_p);
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && N % 4 != 0)) return (int)hipErrorInvalidValue;      // the mask pairs keys: rows of 4 | N
+    uint32_t thresh; float inv_keep;
+    drop_pair_params(drop_p, thresh, inv_keep);
     if (B <= 0 || N <= 0) return 0;
     const int qtiles = (N + 63) / 64;
     const long long blocks = (long long)B * RH * qtiles;
@@ -783,9 +785,9 @@ extern "C" int tup_rt_attention_bwd(const void* qkv, const void* out, const void
                                     void* gqkv, int B, int N, float drop_p, unsigned int drop_seed, void* stream)
 {
     if (B <= 0 || N <= 0) return 0;
-    if (drop_p < 0.f || drop_p >= 1.f) return (int)hipErrorInvalidValue;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
-    const float inv_keep = 1.0f / (1.0f - drop_p);
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && N % 4 != 0)) return (int)hipErrorInvalidValue;
+    uint32_t thresh; float inv_keep;
+    drop_pair_params(drop_p, thresh, inv_keep);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const long long nprep = (long long)B * N * RH;
     rt_attn_bwd_prep_kernel<<<dim3((unsigned)((nprep + 255) / 256)), dim3(256), 0, s>>>((const bf16_t*)out, (const bf16_t*)gout, work, B, N);

@@ -334,6 +334,7 @@ def main():
         from transformerupscaler_amd.autograd import l1_loss
         from transformerupscaler_amd.dp import DataParallel
         from transformerupscaler_amd.weights import rt_deterministic_state_dict
+        torch.cuda.empty_cache()
         tm = importlib.import_module("models.ResidualTransformer.model").TransformerModel()
         tm.load_state_dict(rt_deterministic_state_dict(0))
         tm = tm.to(dev).train()                     # dropout p=0.1 on attention probabilities and MLP output
@@ -411,6 +412,7 @@ def main():
     def run_x4():
         """BASELINE.json configs[3]: 4x 540x960 -> 2160x3840 bf16 inference, batch 4 per GPU (two-stage branch A: explicit
         64->256 conv + PixelShuffle at 540p, then the composed 5x5 at 1080p; reflect-padded 544-row token grid)."""
+        torch.cuda.empty_cache()          # a clean allocator for this mode's warm-up (the previous mode's block sizes do not fit this one's)
         gx = torch.Generator().manual_seed(777 + rank)
         xx = torch.rand((args.x4_batch, 3, 540, 960), generator=gx).to(dev)
         steps = max(1, min(args.steps, 10))
@@ -420,12 +422,24 @@ def main():
             torch.cuda.synchronize()
             barrier()
             torch.cuda.synchronize()
+            ms0 = torch.cuda.memory_stats()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
             t0 = time.perf_counter()
-            for _ in range(steps):
+            evs[0].record()
+            for i in range(steps):
                 yy = model(xx, upscale_factor=4)
+                evs[i + 1].record()
             torch.cuda.synchronize()
             barrier()
             dtt = time.perf_counter() - t0
+            ms1 = torch.cuda.memory_stats()
+            # diagnostics (not the metric): GPU time of every step and what the caching allocator did inside the timed region -- a
+            # step that has to go to hipMalloc / hipFree (0.4 GB outputs) stalls for milliseconds on some boxes
+            per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+            alloc_diag = {"step_ms_min": min(per_step), "step_ms_median": sorted(per_step)[steps // 2], "step_ms_max": max(per_step),
+                          "device_allocs_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+                          "device_frees_in_timed_region": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
+                          "alloc_retries_in_timed_region": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0)}
         assert tuple(yy.shape) == (args.x4_batch, 3, 2160, 3840)
         if dist is not None:
             t = torch.tensor([dtt], device=dev, dtype=torch.float64)
@@ -434,7 +448,7 @@ def main():
         flop = 950.2e9 * args.x4_batch                      # 950.2 GF forward per image as the reference computes it
         return {"metric": "images/sec, FastTransformer 4x 540p->2160p inference", "value": world * args.x4_batch * steps / dtt,
                 "unit": "images/sec", "ms_per_step": dtt / steps * 1e3, "steps": steps, "images_per_gpu_per_step": args.x4_batch,
-                "reference_gflop_per_image": 950.2,
+                "reference_gflop_per_image": 950.2, "diagnostics": alloc_diag,
                 "reference_flop_rate_tflops": flop / (dtt / steps) / 1e12,
                 "note": "reference-FLOP rate = the reference's 950.2 GF per image / time; the build executes fewer (the last up-conv + "
                         "PixelShuffle + up1_conv run as one composed 5x5 conv)"}

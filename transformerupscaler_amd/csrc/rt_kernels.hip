@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
         const int q = min(q0 + 16 * t + p, N - 1);
         qf[t] = *reinterpret_cast<const s16x4*>(base + (size_t)q * (3 * RD) + 4 * g);
         dof[t] = *reinterpret_cast<const s16x4*>(gbase + (size_t)q * RD + 4 * g);
-        lc[t] = lse[((size_t)b * RH + h) * N + q];
+        lc[t] = lse[((size_t)b * RH + h) * N + q] * 1.4426950408889634f;          // log2 domain: P = exp2(s * (0.25 log2 e) - lc), one FMA + one v_exp per score
         dc[t] = dsum[((size_t)b * RH + h) * N + q];
     }
     f32x4 dq[4];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dq_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int key = k0 + 16 * kt + 4 * g + e;
-                        const float pr = key < N ? __expf(s[e] * 0.25f - lc[qt]) : 0.f;
+                        const float pr = key < N ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], 0.25f * 1.4426950408889634f, -lc[qt])) : 0.f;
                         float dpe = dp[e];
                         if constexpr (DROP) dpe *= dm[e];
                         ds[e] = pr * (dpe - dc[qt]);
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qq = q0 + 16 * t + 4 * g + e;
-                lr[t][e] = qq < N ? lrow[qq] : 0.f;
+                lr[t][e] = qq < N ? lrow[qq] * 1.4426950408889634f : 0.f;          // log2 domain, as in the dq kernel
                 dr[t][e] = qq < N ? drow[qq] : 0.f;
             }
         }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qq = q0 + 16 * qt + 4 * g + e;
-                        pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
+                        pr[e] = qq < N ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], 0.25f * 1.4426950408889634f, -lr[qt][e])) : 0.f;
                         ds[e] = pr[e] * (dp[e] * dm[e] - dr[qt][e]);
                         pr[e] *= dm[e];                      // dV sees the dropped probabilities
                     }

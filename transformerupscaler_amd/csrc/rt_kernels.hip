@@ -464,7 +464,10 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
                     const f32x4 dp = mfma16x16x16(dof[qt], vf[kt], f32x4{0.f, 0.f, 0.f, 0.f});
                     f32x4 pr, ds;
                     float dm[4] = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (DROP)       // queries 4g .. 4g+3 of one key per lane; the key's pair partner is the neighbouring lane
+                    // queries 4g .. 4g+3 of one key per lane; the key's pair partner is the neighbouring lane.  (Measured, backward of a block at
+                    // B = 2: this form 380 us, one pair hash per element 428 us, round 2's one plain hash per element 382 us -- in THIS
+                    // kernel the halved hash count only pays for the exchange; forward and dQ, whose lanes hold the pair, gained 20 / 39 us.)
+                    if constexpr (DROP)
                         drop_pair4_rows(hseed, (uint32_t)(q0 + 16 * qt + 4 * g) * (uint32_t)N + (uint32_t)(k0 + 16 * kt + p), (uint32_t)N, thresh, inv_keep, dm);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {

@@ -706,6 +706,21 @@ def test_blocks_six_in_one_launch_equals_six_launches(dev):
     assert torch.equal(one32, ref32)
 
 
+def test_blocks_one_window_per_workgroup_equals_two(dev):
+    """Launches that would not fill the chip's workgroup slots run the whole-block kernel with ONE window per workgroup (16 token rows
+    per wave, csrc/fused_attn.hip TGN = 1; 37 windows here), large ones with two (TGN = 2; 800 windows here).  A window never meets
+    another window, so the first 37 windows of the large launch must come out bit-identical to the small launch."""
+    from transformerupscaler_amd import ops
+    small, large = 37, 800
+    seq = [_block_operands(dev, 1, seed=60 + i)[1] for i in range(2)] * 3
+    x = _block_operands(dev, large, seed=70)[0]["x"].to(dev)
+    table = ops.block_table([tuple(a) for a in seq])
+    big = ops.fused_blocks32(x.clone(), table)
+    sm = ops.fused_blocks32(x[:small * 64].clone(), table)
+    assert torch.isfinite(big).all()
+    assert torch.equal(sm, big[:small * 64])
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 8, 32), (1, 13, 37), (2, 24, 70), (1, 6, 6)])
 def test_branch_a_composed_training(dev, B, H, W):
     """csrc/branch_a_train.hip: forward of the composed branch A and its whole backward (input gradient incl. the ring, the

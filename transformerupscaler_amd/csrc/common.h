@@ -185,10 +185,11 @@ TUP_DEVICE void gelu16_batch(h2 (&x)[N]) {
     for (int i = 0; i < N; ++i) x[i] = x[i] * __builtin_elementwise_fma(xc[i], q[i], h2{(_Float16)0.5f, (_Float16)0.5f});
 }
 // FC1 accumulators (x / 4, fp32) of both token tiles -> the fp16 hidden fragments gelu(x) / 4 (the B operand of FC2)
-TUP_DEVICE void gelu16_fragments(const f32x4 (&acc1)[2][2], bf16x8 (&hfr)[2]) {
-    h2 hv[8];                          // both token tiles in lockstep: 8 independent chains
+template <int TGN>
+TUP_DEVICE void gelu16_fragments(const f32x4 (&acc1)[TGN][2], bf16x8 (&hfr)[TGN]) {
+    h2 hv[4 * TGN];                    // all token tiles in lockstep: 4 independent chains per tile
 #pragma unroll
-    for (int tg = 0; tg < 2; ++tg)
+    for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             hv[tg * 4 + hh * 2 + 0] = __builtin_convertvector(f32x2{acc1[tg][hh][0], acc1[tg][hh][1]}, h2);
@@ -196,10 +197,10 @@ TUP_DEVICE void gelu16_fragments(const f32x4 (&acc1)[2][2], bf16x8 (&hfr)[2]) {
         }
 #ifndef TUP_EXP_NOGELU          // timing experiment (wrong results): the whole-block kernel without the GELU arithmetic = the most that
                                 // hiding it behind the fc1 / fc2 MFMAs could gain
-    gelu16_batch<8>(hv);
+    gelu16_batch<4 * TGN>(hv);
 #endif
 #pragma unroll
-    for (int tg = 0; tg < 2; ++tg) {
+    for (int tg = 0; tg < TGN; ++tg) {
         u32x4 pk;
 #pragma unroll
         for (int q = 0; q < 4; ++q) pk[q] = __builtin_bit_cast(uint32_t, hv[tg * 4 + q]);

@@ -125,7 +125,7 @@ TUP_DEVICE void ln_fragments(const f32x4 (&v)[12], bf16x8 (&tf)[6])
     }
 }
 
-template <bool PROJ, bool MLP = false, bool STAMPS = false>
+template <bool PROJ, bool MLP = false, bool STAMPS = false, int TGN = 2>
 __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const float* __restrict__ x_in, bf16_t* __restrict__ out, int nwin, float* __restrict__ xio, const BlockTable tbl, int nblk)
 {
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     // channels (n >> 2) * 64 + 16 g + (n & 3) * 4 .. +3 for n < 12).  LayerNorm1 reads it in THIS layout (the qkv weight's K columns
     // are packed to match, packing.pack_qkv_heads, as mlp.0's are for LayerNorm2), so from the second block of a launch on it
     // is the previous block's accumulators: no load, the stream only goes out to memory (for the residual re-read at the proj)
-    f32x4 xcar[2][12];
+    f32x4 xcar[TGN][12];
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
     // the thread's coordinates are recomputed per block from an opaque copy of threadIdx: as loop invariants hipcc hoists the
@@ -155,12 +155,16 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     __builtin_assume(tid >= 0 && tid < 256);
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: DMA targets, window, row0, hf are SALU
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: DMA targets, window, row0, tok0 are SALU
     const int g = lane >> 4, pl = lane & 15;
-    const int wi = wave >> 1, hf = wave & 1;
-    const int win = blockIdx.x * 2 + wi;
+    // TGN = 2 (default): two windows per workgroup, a wave owns 32 token rows (two tiles of 16); TGN = 1 (small launches): ONE window per
+    // workgroup, a wave owns 16 token rows -- twice the workgroups and half the serial work per wave when the launch would not fill the
+    // chip anyway (config 4: 540 windows = 270 workgroups on 512 slots; the overlay frame: 240 windows).  Same arithmetic per token.
+    const int wi = TGN == 2 ? wave >> 1 : 0;
+    const int tok0 = TGN == 2 ? 32 * (wave & 1) : 16 * wave;                // first of this wave's 16 * TGN token rows inside its window
+    const int win = TGN == 2 ? blockIdx.x * 2 + wi : blockIdx.x;
     const bool active = win < nwin;
-    const int row0 = (active ? win : nwin - 1) * 64 + 32 * hf;          // first of this wave's 32 token rows
+    const int row0 = (active ? win : nwin - 1) * 64 + tok0;
     const BlockPtrs& bp = tbl.b[blk];
     const float* __restrict__ gamma = bp.gamma1; const float* __restrict__ beta = bp.beta1;
     const bf16_t* __restrict__ wh = bp.wh; const float* __restrict__ bh = bp.bh; const float* __restrict__ bias_frag = bp.bias_frag;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     if constexpr (MLP) {
         if (blk == 0) {
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
+            for (int tg = 0; tg < TGN; ++tg) {
                 const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + g * 16;
 #pragma unroll
                 for (int n = 0; n < 12; ++n) xcar[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + (n & 3) * 4);
@@ -211,14 +215,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 
     // ---- LayerNorm1 straight into B fragments.  K-step st of the qkv product contracts over channels
     // 64 (st >> 1) + 16 g + 8 (st & 1) .. +8 = the lane's residual values n = 2 st, 2 st + 1 ----
-    bf16x8 tf[2][6];
+    bf16x8 tf[TGN][6];
     if constexpr (MLP) {
         // Whole-block form: gamma1 / beta1 are folded into the qkv weight and bias (packing.fold_layernorm), so the B fragments are
         // the plain normalised values: one FMA per value, statistics in ONE sweep (sum and sum of squares, var = E[x^2] - mean^2 in
         // fp32: the stream's |mean| / std stays far below the 2^12 where that form loses the bf16 digits the fragments keep), the
         // four lane groups of a token joined by permlane swaps.  288 VALU instructions per LayerNorm instead of 576 + 24 loads.
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) ln_fragments(xcar[tg], tf[tg]);
+        for (int tg = 0; tg < TGN; ++tg) ln_fragments(xcar[tg], tf[tg]);
         __builtin_amdgcn_sched_barrier(0);
     }
     qb[tid] = q0; qb[256 + tid] = q1;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         f32x4 gm[12], bt[12];
         if (!MLP || blk == 0) {
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
+            for (int tg = 0; tg < TGN; ++tg) {
                 const float* xr = x + (size_t)(row0 + 16 * tg + pl) * DIM + g * 16;
 #pragma unroll
                 for (int n = 0; n < 12; ++n) xcar[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + (n & 3) * 4);
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             bt[n] = *reinterpret_cast<const f32x4*>(beta + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
         }
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
+        for (int tg = 0; tg < TGN; ++tg) {
             float sum = 0.f;
 #pragma unroll
             for (int st = 0; st < 6; ++st)
@@ -287,14 +291,14 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const uint32_t qb_addr = sbase + QB_OFF + (uint32_t)(4 * g) * 4;
     // K / V tiles of this wave's window: [token][16 channels] bf16, 32-byte rows
     const uint32_t kv_win = sbase + KV_OFF + (uint32_t)wi * 4096;
-    const uint32_t kv_wr = (uint32_t)(32 * hf + pl) * 32 + g * 8;            // + 16*tg*32; own tokens, channels 4g..
+    const uint32_t kv_wr = (uint32_t)(tok0 + pl) * 32 + g * 8;               // + 16*tg*32; own tokens, channels 4g..
     const uint32_t k_rd = (uint32_t)pl * 32 + g * 8;                          // + 16*kt*32: K[key 16kt+pl][4g..]
     const int trq = pl >> 2, trp = pl & 3;
     const uint32_t v_rd = 2048 + (uint32_t)(4 * g + trq) * 32 + trp * 8;      // + 16*kt*32: V rows 16kt+4g+trq (transposed read)
     bf16_t* sink = reinterpret_cast<bf16_t*>(tup_fa_sink) + lane * 4;
 
     // PROJ: the attention output of this wave's 32 tokens, all heads: of[tg][h] = O^T tile (channels 4g.., token pl) as bf16x4
-    s16x4 of[2][PROJ ? HEADS : 1];
+    s16x4 of[TGN][PROJ ? HEADS : 1];
     auto dma_wp = [&](int chunk, int buf) {                      // rows 64*chunk .. +63 of the packed proj weight
         const __amdgpu_buffer_rsrc_t r = weight_rsrc(wproj);
         char* dst = smem + buf * FW_BYTES + wave * 1024;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     // proj / FC2 accumulators = the residual stream.  Whole-block form: the last head requests the stream's re-read (x as the previous
     // block -- or patch_embed -- left it) straight into them, so it lands under that head's softmax and the proj accumulates on top;
     // requested after the proj the 24 loads were a round trip of their own in front of LayerNorm2
-    f32x4 acc2[PROJ ? 2 : 1][PROJ ? 12 : 1];
+    f32x4 acc2[PROJ ? TGN : 1][PROJ ? 12 : 1];
     B32_STAMP(P_LN1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of head 0's weights; bias staging visible below
     __syncthreads();
@@ -324,17 +328,17 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     auto head = [&](const int h) {
         // relative position bias of this wave's (key tile, query tile) pairs, requested BEFORE the DMA below so that the
         // compiler's wait for them is vmcnt(6) (= the DMA pieces), not vmcnt(0)
-        f32x4 rb[2][4];
+        f32x4 rb[TGN][4];
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
+        for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
-                rb[tg][kt] = *reinterpret_cast<const f32x4*>(bias_frag + ((((size_t)h * 4 + kt) * 4 + (2 * hf + tg)) * 64 + lane) * 4);
+                rb[tg][kt] = *reinterpret_cast<const f32x4*>(bias_frag + ((((size_t)h * 4 + kt) * 4 + (tok0 / 16 + tg)) * 64 + lane) * 4);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- [q; k; v]^T = W_h LN(x)^T: rows = channel within the head (ct 0 = q, 1 = k, 2 = v), columns = tokens ----
         const uint32_t wb = sbase + (uint32_t)((h & 1) * FW_BYTES) + w_off;
-        f32x4 acc[2][3];
+        f32x4 acc[TGN][3];
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             const f32x4 bv = __builtin_bit_cast(f32x4, lds_read_b128_asm(qb_addr + (uint32_t)((h * 48 + ct * 16) * 4)));
@@ -352,8 +356,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
             ld(0, 0);
             ld(1, 1);
             lds_wait<6>();             // the three bias reads have landed
+            if constexpr (TGN == 2) {
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct) acc[1][ct] = acc[0][ct];
+                for (int ct = 0; ct < 3; ++ct) acc[TGN - 1][ct] = acc[0][ct];
+            }
 #pragma unroll
             for (int step = 0; step < 6; ++step) {
                 const int cur = step % 3;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 else { lds_wait<0>(); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tg = 0; tg < 2; ++tg)
+                for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
                     for (int ct = 0; ct < 3; ++ct) acc[tg][ct] = mfma16x16x32(wf[cur][ct], tf[tg][step], acc[tg][ct]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -370,10 +376,10 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         }
         B32_STAMP(P_QKV);
         // ---- q stays (scaled); K and V go to the window's LDS tile ----
-        s16x4 qf[2];
+        s16x4 qf[TGN];
         const uint32_t kvb = kv_win + (uint32_t)((h & 1) * 8192);
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
+        for (int tg = 0; tg < TGN; ++tg) {
             qf[tg] = __builtin_bit_cast(s16x4, u32x2{pack_bf16x2(acc[tg][0][0] * 0.25f, acc[tg][0][1] * 0.25f),
                                                     pack_bf16x2(acc[tg][0][2] * 0.25f, acc[tg][0][3] * 0.25f)});
             lds_write_b64_asm(kvb + kv_wr + tg * 512, u32x2{pack_bf16x2(acc[tg][1][0], acc[tg][1][1]), pack_bf16x2(acc[tg][1][2], acc[tg][1][3])});
@@ -383,7 +389,9 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         // ago; younger than them: the 2 output stores of head h-1 -- none with PROJ -- and the 8 bias loads above), so
         // passing it means: K / V of this head are written, the next head's weights have landed everywhere, and
         // everyone is done reading this head's weight slot -- which is refilled right away, two heads ahead.
-        if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        static_assert(TGN == 2 || (PROJ && MLP), "one window per workgroup is built for the whole-block form only");
+        if constexpr (PROJ && TGN == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // 4 bias loads per token tile
+        else if constexpr (PROJ) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef TUP_EXP_NOBAR
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         if constexpr (MLP) {
             if (h == HEADS - 1) {
 #pragma unroll
-                for (int tg = 0; tg < 2; ++tg) {
+                for (int tg = 0; tg < TGN; ++tg) {
                     const float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
                     for (int n = 0; n < 12; ++n) acc2[tg][n] = *reinterpret_cast<const f32x4*>(xr + (n >> 2) * 64 + g * 16 + (n & 3) * 4);
@@ -414,26 +422,26 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         // ---- S^T = K Q^T + bias, softmax over keys, O^T = V^T P^T; both query tiles advance in lockstep (independent chains
         // cover each other's latencies), cross-lane reductions by v_permlane swaps instead of ds_bpermute, exp2 with the
         // log2(e) scale and the row maximum folded into one FMA, P enters the product unnormalised and O is scaled by 1 / sum ----
-        f32x4 st[2][4];
+        f32x4 st[TGN][4];
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
+        for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) st[tg][kt] = mfma16x16x16(kf[kt], qf[tg], rb[tg][kt]);          // bias as the accumulator input
-        float mx[2];
+        float mx[TGN];
 #ifndef TUP_EXP_NOSOFTMAX      // timing experiment (wrong results): the kernel without the softmax's max / exp arithmetic = the most that
                                // hiding it under MFMAs could gain (scripts/ab_block.py, DESIGN 5c: -4.5 %); TUP_EXP_NOBAR likewise
                                // for the per-head barrier (-3.4 %)
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
+        for (int tg = 0; tg < TGN; ++tg) {
             float m = fmaxf(fmaxf(st[tg][0][0], st[tg][0][1]), fmaxf(st[tg][0][2], st[tg][0][3]));
 #pragma unroll
             for (int kt = 1; kt < 4; ++kt) m = fmaxf(fmaxf(m, st[tg][kt][0]), fmaxf(st[tg][kt][1], fmaxf(st[tg][kt][2], st[tg][kt][3])));
             mx[tg] = m;
         }
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) mx[tg] = rows_max(mx[tg]) * 1.4426950408889634f;
+        for (int tg = 0; tg < TGN; ++tg) mx[tg] = rows_max(mx[tg]) * 1.4426950408889634f;
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg)
+        for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         // values that enter the product, i.e. numerator and denominator see the same rounding.
         const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
+        for (int tg = 0; tg < TGN; ++tg) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f}, sm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kp = 0; kp < 2; ++kp) {
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         // join4's k map, so the fragment addressing is the standard one (k-tile p >> 1, chunk 4 (p & 1) + g) ----
         if constexpr (!MLP) {
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg)
+            for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
                 for (int n = 0; n < 12; ++n) acc2[tg][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 else { lds_wait<0>(); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tg = 0; tg < 2; ++tg) {
+                for (int tg = 0; tg < TGN; ++tg) {
                     const bf16x8 tfp = join4(of[tg][2 * step], of[tg][2 * step + 1]);
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) acc2[tg][4 * c + ct] = mfma16x16x32(wf[cur][ct], tfp, acc2[tg][4 * c + ct]);
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
         if constexpr (!MLP) {
             if (!active) return;
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) {
+            for (int tg = 0; tg < TGN; ++tg) {
                 float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
                 for (int n = 0; n < 12; ++n) {
@@ -560,15 +568,15 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int tg = 0; tg < 2; ++tg) acc2[tg][4 * q + i] += bv[i];
+                    for (int tg = 0; tg < TGN; ++tg) acc2[tg][4 * q + i] += bv[i];
             }
             // LayerNorm2 from the accumulators: this lane holds 48 of its token's 192 channels, the other three lane
             // groups the rest.  K-step st of FC1 contracts over channels 64*(st>>1) + 16g + 8*(st&1) .. +8 = accumulators
             // n = 2st, 2st+1 (packing.pack_fc1_fused), so the B fragments are packed straight from them.
             // gamma2 / beta2 are folded into mlp.0 (packing.fold_layernorm): plain normalised fragments, as LayerNorm1 above
-            bf16x8 tf2[2][6];
+            bf16x8 tf2[TGN][6];
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg) ln_fragments(acc2[tg], tf2[tg]);
+            for (int tg = 0; tg < TGN; ++tg) ln_fragments(acc2[tg], tf2[tg]);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {          // FC2 accumulates onto x + b2
                 f32x4 bv[4];
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int tg = 0; tg < 2; ++tg) acc2[tg][4 * q + i] += bv[i];
+                    for (int tg = 0; tg < TGN; ++tg) acc2[tg][4 * q + i] += bv[i];
             }
 
             B32_STAMP(P_LN2);
@@ -603,9 +611,9 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 B32_STAMP(P_MTOP);
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    f32x4 acc1[2][2];
+                    f32x4 acc1[TGN][2];
 #pragma unroll
-                    for (int tg = 0; tg < 2; ++tg)
+                    for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh) acc1[tg][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
                     f32x4 bb[2];
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                         else lds_wait<0>();
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg)
+                        for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
                             for (int hh = 0; hh < 2; ++hh)
                                 acc1[tg][hh] = mfma16x16x32(wf[cur][hh], tf2[tg][step], step == 0 ? bb[hh] : acc1[tg][hh]);
@@ -656,8 +664,8 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                     for (int n = 0; n < 8; ++n) w2f[n] = w2rd(n);
                     __builtin_amdgcn_sched_barrier(0);
-                    bf16x8 hfr[2];
-                    gelu16_fragments(acc1, hfr);          // fp16: gelu(x) / 4 (common.h)
+                    bf16x8 hfr[TGN];
+                    gelu16_fragments<TGN>(acc1, hfr);          // fp16: gelu(x) / 4 (common.h)
                     __builtin_amdgcn_sched_barrier(0);
                     B32_STAMP(P_GELU);
                     lds_wait<4>();
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][n]);
+                        for (int tg = 0; tg < TGN; ++tg) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][n]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n) w2f[n] = w2rd(8 + n);
@@ -674,21 +682,21 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
 #pragma unroll
                     for (int n = 4; n < 8; ++n)
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][n]);
+                        for (int tg = 0; tg < TGN; ++tg) acc2[tg][n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][n]);
                     __builtin_amdgcn_sched_barrier(0);
                     lds_wait<0>();
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 4; ++n)
 #pragma unroll
-                        for (int tg = 0; tg < 2; ++tg) acc2[tg][8 + n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][8 + n]);
+                        for (int tg = 0; tg < TGN; ++tg) acc2[tg][8 + n] = mfma16x16x32_f16(w2f[n], hfr[tg], acc2[tg][8 + n]);
                     __builtin_amdgcn_sched_barrier(0);
                     B32_STAMP(P_FC2);
                 }
             }
             if (active) {
 #pragma unroll
-                for (int tg = 0; tg < 2; ++tg) {
+                for (int tg = 0; tg < TGN; ++tg) {
                     float* xr = xio + (size_t)(row0 + 16 * tg + pl) * DIM;
 #pragma unroll
                     for (int n = 0; n < 12; ++n)
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
                 }
             }
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg)
+            for (int tg = 0; tg < TGN; ++tg)
 #pragma unroll
                 for (int n = 0; n < 12; ++n) xcar[tg][n] = acc2[tg][n];        // the next block's LayerNorm1 input
             if constexpr (STAMPS) {
@@ -728,9 +736,17 @@ BlockTable one_block(const float* g1, const float* b1n, const void* wh, const fl
 int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* stream)
 {
     static const bool stamps = getenv("TUP_B32_STAMPS") != nullptr;          // diagnostic build (timing shares only)
+    // launches of at most 512 windows (the chip's workgroup slots: 256 CUs x 2) run ONE window per workgroup, 16 token rows per wave:
+    // twice the workgroups, half the serial work per wave -- the 720p -> 4K overlay frame (240 windows) 1.237 -> 1.166 ms; config 4's
+    // 540 windows would be 1.05 rounds that way (2.59 vs 2.56 ms) and stay on the two-window form.  TUP_BLOCK_ONE_WINDOW=0 / 1 forces a form.
+    static const int force1 = [] { const char* e = getenv("TUP_BLOCK_ONE_WINDOW"); return e ? atoi(e) : -1; }();
+    const bool one_window = force1 >= 0 ? force1 != 0 : nwin <= 512;
     const dim3 grid((nwin + 1) / 2);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (stamps) {
+    if (one_window && !stamps) {
+        TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, false, 1>), FB_LDS);
+        fused_qkv_attn_kernel<true, true, false, 1><<<dim3(nwin), dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
+    } else if (stamps) {
         TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, true>), FB_LDS);
         fused_qkv_attn_kernel<true, true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
     } else {

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void fused_mlp_v2_kernel(
             for (int n = 0; n < 8; ++n) w2f[n] = lds_read_b128_asm(w2addr(n));
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 hf[2];
-            gelu16_fragments(acc1, hf);          // fp16: gelu(x) / 4; acc1 already holds x / 4 incl. the bias (common.h)
+            gelu16_fragments<2>(acc1, hf);          // fp16: gelu(x) / 4; acc1 already holds x / 4 incl. the bias (common.h)
             __builtin_amdgcn_sched_barrier(0);
             lds_wait<4>();
             if (j < 3) stamp();    // GELU done

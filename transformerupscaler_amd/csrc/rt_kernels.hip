@@ -472,11 +472,7 @@ __global__ __launch_bounds__(256) void rt_attn_bwd_dkv_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qq = q0 + 16 * qt + 4 * g + e;
-                        #ifdef TUP_EXP_DKV_EXPF
-                        pr[e] = qq < N ? __expf(s[e] * 0.25f - lr[qt][e]) : 0.f;
-#else
-                        pr[e] = qq < N ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], 0.25f * 1.4426950408889634f, -lr[qt][e])) : 0.f;
-#endif
+                                                pr[e] = qq < N ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], 0.25f * 1.4426950408889634f, -lr[qt][e])) : 0.f;      // (vs __expf: 378 vs 383 us per backward)
                         ds[e] = pr[e] * (dp[e] * dm[e] - dr[qt][e]);
                         pr[e] *= dm[e];                      // dV sees the dropped probabilities
                     }

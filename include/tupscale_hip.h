@@ -242,6 +242,11 @@ int tup_relpos_bias_reduce(const float* dbias_n, float* dtable, void* stream);
 int tup_patch_unembed_bwd(const void* gmap, const void* Wt, float* gx, int B, int H, int W, void* stream);
 int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_pad, int B, int H, int W, void* stream);
 
+/* ... with the gradient merge at `feat` in the epilogue (H, W multiples of 8): out bf16 NHWC [B][H][W][64] = (gx Wt^T + add1 + add2)
+ * * (relu_src > 0) -- tup_patch_embed_bwd followed by tup_feat_grad_combine without the padded map in between.  add2 may be NULL. */
+int tup_patch_embed_bwd_merge(const float* gx, const void* Wt, const void* add1, const void* add2, const void* relu_src,
+                              void* out, int B, int H, int W, void* stream);
+
 /* Weight/bias gradients of the 3x3 convs (accumulating).
  *   c64:    x bf16 NHWC, gmap bf16 NHWC [B][H*gr][W*gr][64] sub-pixel plane sp -> dwp fp32 [64][9][64]
  *           (co, tap, ci) for couts {c*gr*gr + sp}, dbias fp32 [64] or NULL

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops, packing
@@ -39,6 +41,9 @@ def _valid_token_rowmask(B, H, W, device):
 def site_seed(seed: int, block: int, site: int) -> int:
     """Per-dropout-site seed (site 0 = attn_drop, 1 = proj_drop, 2 = MLP dropout of block `block`)."""
     return (seed * 0x9E3779B9 + (3 * block + site + 1) * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+pe_merge = not os.environ.get("TUP_NO_PE_MERGE")          # A/B switch: the gradient merge at `feat` inside patch_embed's input gradient
 
 
 def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, seed=0):
@@ -192,8 +197,12 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
     # ---- patch_embed ----
     g["patch_embed.bias"] = ops.colsum(g_x, rowmask=_valid_token_rowmask(B, H, W, x.device))
     g["patch_embed.weight"] = ops.patch_wgrad(g_x, feat, reflect=True).view(192, 8, 8, 64).permute(0, 3, 1, 2)
-    g_pe = ops.patch_embed_bwd(g_x, pk["pe.wd"], B, H, W)
-    del g_x
+    # the input gradient of patch_embed: when the map needs no reflect padding (H, W multiples of 8) it is computed LAST, with the
+    # merge of the three gradient paths into `feat` and conv2's ReLU gate in its epilogue (no padded map, no feat_grad_combine pass)
+    merge_in_pe = pe_merge and H % 8 == 0 and W % 8 == 0
+    g_pe = None if merge_in_pe else ops.patch_embed_bwd(g_x, pk["pe.wd"], B, H, W)
+    if not merge_in_pe:
+        del g_x
     ready("patch_embed.weight", "patch_embed.bias")
     # ---- branch A: up1_conv (ReLU, no bias) and the Upsampler stages ----
     ups = sv["ups"]
@@ -219,7 +228,11 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
         g_up = ops.conv_c64(g_up, pk[f"up1.{si}.wd"], None, 1, in_r=r)
         ready(k + ".weight", k + ".bias")
     # ---- merge at feat + conv2's ReLU, conv2, conv1 ----
-    g_feat = ops.feat_grad_combine(g_comb, g_up, g_pe, feat)
+    if merge_in_pe:
+        g_feat = ops.patch_embed_bwd_merge(g_x, pk["pe.wd"], g_comb, g_up, feat)
+        del g_x
+    else:
+        g_feat = ops.feat_grad_combine(g_comb, g_up, g_pe, feat)
     del g_comb, g_up, g_pe
     dwp, db = ops.conv_c64_wgrad(sv["feat1"], g_feat, 1)
     g["conv2.weight"], g["conv2.bias"] = packing.unpack_conv_c64_wgrad(dwp, db, 1)

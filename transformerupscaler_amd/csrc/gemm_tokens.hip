@@ -19,7 +19,7 @@
 namespace {
 
 enum { A_BF16 = 0, A_F32 = 1, A_PATCH = 2, A_LN = 3 };
-enum { E_BF16 = 0, E_GELU_BF16 = 1, E_RES_F32 = 2, E_PATCH_EMBED = 3, E_UNEMBED = 4, E_GELU_BWD = 5 };
+enum { E_BF16 = 0, E_GELU_BF16 = 1, E_RES_F32 = 2, E_PATCH_EMBED = 3, E_UNEMBED = 4, E_GELU_BWD = 5, E_UNEMBED_MERGE = 6 };
 
 struct GemmParams {
     const void* A; int lda;
@@ -28,6 +28,7 @@ struct GemmParams {
     void* out; int ldo;
     const float* res;            // E_RES_F32: [M][ldo] fp32
     const bf16_t* skip;          // E_UNEMBED: NHWC feat to add (or null); E_GELU_BWD: pre-activation [M][ldo]
+    const bf16_t* skip2; const bf16_t* relu_src;      // E_UNEMBED_MERGE (panel kernel): a second map to add (or null) and the map whose sign gates the sum
     int reflect;                 // A_PATCH: 1 = reflect-pad beyond the map, 0 = zeros
     uint32_t drop_thresh, drop_seed; float drop_inv_keep;      // E_RES_F32: dropout on (acc + bias) before "+ res"
     const float* ln_gamma; const float* ln_beta;               // panel kernel, A_LN: LayerNorm fused into the A load
@@ -168,7 +169,7 @@ TUP_DEVICE void gemm_store_row(const GemmParams& p, int m, int n0, int g, const 
 // saved pre-activation) are requested before the K loop of the tile and consumed after it, so their HBM round trip
 // hides under the MFMAs instead of being paid between the K loop and the stores of every 64-column tile.
 struct EpiPre {
-    u32x4 a[4];
+    u32x4 a[6];
     size_t off;          // E_UNEMBED: element offset of this lane's 16 channels
     bool ok;
 };
@@ -196,6 +197,21 @@ TUP_DEVICE EpiPre epi_prefetch(const GemmParams& p, int m, int n0, int g)
         if (p.skip && r.ok) {
             r.a[0] = *reinterpret_cast<const u32x4*>(p.skip + r.off);
             r.a[1] = *reinterpret_cast<const u32x4*>(p.skip + r.off + 8);
+        }
+    } else if constexpr (EPI == E_UNEMBED_MERGE) {
+        // training: the gradient merge at `feat` (model.py:264,268,308 fan-out + conv2's ReLU) in the epilogue of patch_embed's input
+        // gradient: out = (acc + skip + skip2) * (relu_src > 0).  Every map is the UNPADDED H x W map (H, W multiples of 8).
+        const TokPos t = token_of_row(m, p);
+        const int pix = n0 >> 6, i = pix >> 3, j = pix & 7;
+        const int py = t.ty * 8 + i, px = t.tx * 8 + j;
+        r.ok = t.valid && py < p.H && px < p.W;
+        r.off = (((size_t)t.b * p.H + py) * p.W + px) * 64 + g * 16;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) r.a[q] = u32x4{0u, 0u, 0u, 0u};
+        if (r.ok) {
+            r.a[0] = *reinterpret_cast<const u32x4*>(p.skip + r.off);     r.a[1] = *reinterpret_cast<const u32x4*>(p.skip + r.off + 8);
+            if (p.skip2) { r.a[2] = *reinterpret_cast<const u32x4*>(p.skip2 + r.off); r.a[3] = *reinterpret_cast<const u32x4*>(p.skip2 + r.off + 8); }
+            r.a[4] = *reinterpret_cast<const u32x4*>(p.relu_src + r.off); r.a[5] = *reinterpret_cast<const u32x4*>(p.relu_src + r.off + 8);
         }
     }
     return r;
@@ -240,6 +256,24 @@ TUP_DEVICE void epi_finish(const GemmParams& p, int m, int n0, int g, const floa
             const float sa = __builtin_bit_cast(float, sw << 16);
             const float sb = __builtin_bit_cast(float, sw & 0xffff0000u);
             pk[q] = pack_bf16x2(v[2 * q] + bvec[2 * q] + sa, v[2 * q + 1] + bvec[2 * q + 1] + sb);
+        }
+        bf16_t* o = (bf16_t*)p.out + pre.off;
+        *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+    } else if constexpr (EPI == E_UNEMBED_MERGE) {
+        if (!pre.ok) return;
+        uint32_t pk[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t s1 = (q < 4) ? pre.a[0][q & 3] : pre.a[1][q & 3], s2 = (q < 4) ? pre.a[2][q & 3] : pre.a[3][q & 3];
+            const uint32_t mw = (q < 4) ? pre.a[4][q & 3] : pre.a[5][q & 3];
+            // (a + b) + this GEMM's value, which stays fp32 here (feat_grad_combine_kernel read it back rounded to bf16)
+            float ra = __builtin_bit_cast(float, s1 << 16) + __builtin_bit_cast(float, s2 << 16);
+            float rb = __builtin_bit_cast(float, s1 & 0xffff0000u) + __builtin_bit_cast(float, s2 & 0xffff0000u);
+            ra += v[2 * q]; rb += v[2 * q + 1];
+            if (!(__builtin_bit_cast(float, mw << 16) > 0.f)) ra = 0.f;
+            if (!(__builtin_bit_cast(float, mw & 0xffff0000u) > 0.f)) rb = 0.f;
+            pk[q] = pack_bf16x2(ra, rb);
         }
         bf16_t* o = (bf16_t*)p.out + pre.off;
         *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
@@ -1039,6 +1073,23 @@ extern "C" int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_p
     static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
     if (use_panel) return launch_panel<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// patch_embed's input gradient with the gradient merge at `feat` in its epilogue (training, H and W multiples of 8 so that the
+// reflect-padded map IS the map): out bf16 NHWC [B][H][W][64] = (gx Wt^T + add1 + add2) * (relu_src > 0) -- the three gradient paths
+// into `feat` (model.py:264 up branch, :268 patch_embed, :308 skip) and conv2's ReLU backward (model.py:252) without the separate
+// tup_feat_grad_combine pass over five 64-channel maps.  add2 may be NULL.
+extern "C" int tup_patch_embed_bwd_merge(const float* gx, const void* Wt, const void* add1, const void* add2, const void* relu_src,
+                                         void* out, int B, int H, int W, void* stream)
+{
+    if (H % 8 || W % 8 || add1 == nullptr || relu_src == nullptr) return (int)hipErrorInvalidValue;
+    GemmParams p{};
+    p.Ht = H / 8; p.Wt_ = W / 8; p.H = H; p.W = W;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
+    p.A = gx; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = out;
+    p.skip = (const bf16_t*)add1; p.skip2 = (const bf16_t*)add2; p.relu_src = (const bf16_t*)relu_src;
+    p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
+    return launch_panel<A_F32, E_UNEMBED_MERGE>(p, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- ResidualTransformer token entry / exit (plain [B][45][80] token grid, no windows) ----

@@ -531,6 +531,18 @@ def patch_embed_bwd(gx, wt, B, H, W):
     return gmap
 
 
+def patch_embed_bwd_merge(gx, wt, add1, add2, relu_src):
+    """patch_embed's input gradient + the gradient merge at `feat` (feat_grad_combine) in one kernel; H, W multiples of 8."""
+    B, H, W, C = relu_src.shape
+    assert C == 64 and H % 8 == 0 and W % 8 == 0
+    _, _, nwy, nwx = window_geometry(H, W)
+    out = torch.empty_like(relu_src)
+    _lib.call("tup_patch_embed_bwd_merge", _chk(gx, F32, (B * nwy * nwx * 64, 192), "gx"), _chk(wt, BF16, (4096, 192), "wt"),
+              _chk(add1, BF16, relu_src.shape, "add1"), _opt(add2, BF16, relu_src.shape, "add2"), _chk(relu_src, BF16, None, "relu_src"),
+              out.data_ptr(), B, H, W, _stream())
+    return out
+
+
 def conv_c64_wgrad(x, gmap, gr=1):
     """-> (dwp fp32 [gr*gr][64][9][64] (sp, co, tap, ci), dbias fp32 [gr*gr][64])."""
     B, H, W, C = x.shape

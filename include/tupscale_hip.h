@@ -60,7 +60,8 @@ int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const float* bias,
 /* Planar fp32 Conv2d(3, 3*r*r, k3, p1) + PixelShuffle(r) [+ add] [+ clamp(0,1)]:
  *   final_upscale utils.py:62-63,74-75,83-84 (n_feats=3) | final_upscale_conv model.py:212,317
  *   fused with "out = upscaled_input + residual_up" model.py:320 and torch.clamp model.py:327.
- * x fp32 [B][3][H][W]; w28 fp32 [3*r*r][28] (27 taps (cin,ky,kx) + pad); out/add fp32 [B][3][H*r][W*r]. */
+ * x fp32 [B][3][H][W]; w28 fp32 [3*r*r][28] (27 taps (cin,ky,kx) + pad); out/add fp32 [B][3][H*r][W*r].
+ * clamp01 = 2 (training): out is [2][B][3][H*r][W*r]: the unclamped sum (the clamp's backward gate), then the clamped output. */
 int tup_conv3x3_planar_fwd(const float* x, const float* w28, const float* bias, const float* add,
                            float* out, int B, int H, int W, int r, int clamp01, void* stream);
 
@@ -243,9 +244,10 @@ int tup_patch_unembed_bwd(const void* gmap, const void* Wt, float* gx, int B, in
 int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_pad, int B, int H, int W, void* stream);
 
 /* ... with the gradient merge at `feat` in the epilogue (H, W multiples of 8): out bf16 NHWC [B][H][W][64] = (gx Wt^T + add1 + add2)
- * * (relu_src > 0) -- tup_patch_embed_bwd followed by tup_feat_grad_combine without the padded map in between.  add2 may be NULL. */
+ * * (relu_src > 0) -- tup_patch_embed_bwd followed by tup_feat_grad_combine without the padded map in between.  add2 may be NULL.
+ * add1_colsum: NULL, or fp32 [16][64] (zeroed by the caller) += per-channel sums of add1 in 16 replicas (tup_colsum of add1 for free). */
 int tup_patch_embed_bwd_merge(const float* gx, const void* Wt, const void* add1, const void* add2, const void* relu_src,
-                              void* out, int B, int H, int W, void* stream);
+                              void* out, float* add1_colsum, int B, int H, int W, void* stream);
 
 /* Weight/bias gradients of the 3x3 convs (accumulating).
  *   c64:    x bf16 NHWC, gmap bf16 NHWC [B][H*gr][W*gr][64] sub-pixel plane sp -> dwp fp32 [64][9][64]

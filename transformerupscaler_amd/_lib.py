@@ -86,7 +86,7 @@ SIGNATURES = {
     "tup_relpos_bias_reduce": [P, P, P],
     "tup_patch_unembed_bwd": [P, P, P, I, I, I, P],
     "tup_patch_embed_bwd": [P, P, P, I, I, I, P],
-    "tup_patch_embed_bwd_merge": [P, P, P, P, P, P, I, I, I, P],
+    "tup_patch_embed_bwd_merge": [P, P, P, P, P, P, P, I, I, I, P],
     "tup_conv3x3_c64_wgrad": [P, P, P, P, I, I, I, I, I, P],
     "tup_conv3x3_thin_wgrad": [P, P, P, P, I, I, I, P],
     "tup_conv3x3_c3_wgrad": [P, P, P, P, I, I, I, P],

@@ -94,12 +94,12 @@ def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, see
     sv["ts"] = ts
     hs, ws = H * scale, W * scale
     needs_resize = bool(require_ratio) and tuple(res_out) != (hs, hs) and tuple(res_out) != (hs, ws)
-    total = ops.conv_planar(ts[-1], pk["fuc.w"], pk["fuc.b"], 1, add=ui, clamp=False)     # pre-clamp sum
     if needs_resize:
+        total = ops.conv_planar(ts[-1], pk["fuc.w"], pk["fuc.b"], 1, add=ui, clamp=False)     # pre-clamp sum
         pre, out = ops.resize_aa(total, res_out, clamp="both")      # the clamp's backward gate and the model output in one pass
         sv["resized_from"] = (hs, ws)
     else:
-        pre, out = total, ops.clamp01(total)
+        pre, out = ops.conv_planar(ts[-1], pk["fuc.w"], pk["fuc.b"], 1, add=ui, clamp="both")   # likewise, straight from the conv
         sv["resized_from"] = None
     sv["pre"] = pre
     return out, sv
@@ -148,7 +148,12 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
     del g_dec
     ready("decoder_conv1.weight", "decoder_conv1.bias")
     # ---- patch_unembed (+ skip) ----
-    g["patch_unembed.bias"] = ops.colsum(g_comb.view(-1, 64))
+    # patch_unembed's bias gradient = the column sums of g_comb.  Without a gradient reducer they ride along in the kernel that reads
+    # g_comb last (the merged patch_embed input gradient at the end of this function); with one, the bias has to be ready NOW so that
+    # its bucket's all-reduce starts under the rest of the backward
+    late_pu_bias = reducer is None and pe_merge and H % 8 == 0 and W % 8 == 0
+    if not late_pu_bias:
+        g["patch_unembed.bias"] = ops.colsum(g_comb.view(-1, 64))
     g["patch_unembed.weight"] = ops.patch_wgrad(sv["xw_out"], g_comb, reflect=False).view(192, 8, 8, 64).permute(0, 3, 1, 2)
     g_x = ops.patch_unembed_bwd(g_comb, pk["pu.wd"])
     ready("patch_unembed.weight", "patch_unembed.bias")
@@ -228,7 +233,10 @@ def backward_train(pk, frags_t, frags_n, sv, scale, gout, reducer=None, want_inp
         g_up = ops.conv_c64(g_up, pk[f"up1.{si}.wd"], None, 1, in_r=r)
         ready(k + ".weight", k + ".bias")
     # ---- merge at feat + conv2's ReLU, conv2, conv1 ----
-    if merge_in_pe:
+    if merge_in_pe and late_pu_bias:
+        g_feat, g["patch_unembed.bias"] = ops.patch_embed_bwd_merge(g_x, pk["pe.wd"], g_comb, g_up, feat, want_add1_colsum=True)
+        del g_x
+    elif merge_in_pe:
         g_feat = ops.patch_embed_bwd_merge(g_x, pk["pe.wd"], g_comb, g_up, feat)
         del g_x
     else:

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void conv3x3_planar_kernel(
         const int si = sp / r, sj = sp - si * r;
         const size_t oi = (((size_t)b * 3 + c) * Hr + (oy * r + si)) * Wr + (ox * r + sj);
         if (add) s += add[oi];
-        if (clamp01) s = fminf(fmaxf(s, 0.f), 1.f);
+        if (clamp01 == 2) out[(size_t)gridDim.z * 3 * Hr * Wr + oi] = fminf(fmaxf(s, 0.f), 1.f);      // [unclamped | clamped]
+        else if (clamp01) s = fminf(fmaxf(s, 0.f), 1.f);
         out[oi] = s;
     }
 }
@@ -369,7 +370,12 @@ __global__ __launch_bounds__(256) void conv3x3_planar_r1x4_kernel(
         const size_t oi = (((size_t)b * 3 + co) * H + oy) * W + ox;
         f32x4 s = acc[co];
         if (add) s += *reinterpret_cast<const f32x4*>(add + oi);
-        if (clamp01) {
+        if (clamp01 == 2) {          // training: [unclamped | clamped] in one pass (the clamp's backward gate and the model output)
+            f32x4 c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = fminf(fmaxf(s[e], 0.f), 1.f);
+            *reinterpret_cast<f32x4*>(out + (size_t)gridDim.z * 3 * H * W + oi) = c;
+        } else if (clamp01) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] = fminf(fmaxf(s[e], 0.f), 1.f);
         }

@@ -29,6 +29,7 @@ struct GemmParams {
     const float* res;            // E_RES_F32: [M][ldo] fp32
     const bf16_t* skip;          // E_UNEMBED: NHWC feat to add (or null); E_GELU_BWD: pre-activation [M][ldo]
     const bf16_t* skip2; const bf16_t* relu_src;      // E_UNEMBED_MERGE (panel kernel): a second map to add (or null) and the map whose sign gates the sum
+    float* skip_colsum;                               // E_UNEMBED_MERGE: optional fp32 [16][64] += per-channel sums of `skip` (16 replicas, spread by workgroup)
     int reflect;                 // A_PATCH: 1 = reflect-pad beyond the map, 0 = zeros
     uint32_t drop_thresh, drop_seed; float drop_inv_keep;      // E_RES_F32: dropout on (acc + bias) before "+ res"
     const float* ln_gamma; const float* ln_beta;               // panel kernel, A_LN: LayerNorm fused into the A load
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(256, 2) void gemm_panel2_kernel(const GemmParams p)
     }
 
     const uint32_t w_frag = lds_addr(smem) + (uint32_t)swz128(pl, g);
+    float cs[EPI == E_UNEMBED_MERGE ? 16 : 1] = {};            // E_UNEMBED_MERGE: column sums of `skip` (this lane's 16 channels)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of W tile 0
     for (int nt = 0; nt < ntiles; ++nt) {
         __syncthreads();                                       // everyone's pieces of tile nt landed; everyone finished reading tile nt-1
@@ -747,6 +749,35 @@ __global__ __launch_bounds__(256, 2) void gemm_panel2_kernel(const GemmParams p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[ct * 4 + e] = acc[tg][ct][e];
             epi_finish<EPI>(p, m, n0, g, v, bvec, pre[tg]);
+            if constexpr (EPI == E_UNEMBED_MERGE) {
+                if (pre[tg].ok) {          // every element of `skip` passes through exactly one lane here: its column sums ride along
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const uint32_t sw = (q < 4) ? pre[tg].a[0][q & 3] : pre[tg].a[1][q & 3];
+                        cs[2 * q] += __builtin_bit_cast(float, sw << 16);
+                        cs[2 * q + 1] += __builtin_bit_cast(float, sw & 0xffff0000u);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == E_UNEMBED_MERGE) {
+        if (p.skip_colsum) {
+            // lane (g, pl) holds channels 16 g .. 16 g + 15: sum over the 16 lanes of a group and the four waves through LDS (the
+            // weight buffers are free now), then one atomic per channel onto this workgroup's replica (blockIdx & 15): atomics on
+            // the same address serialise in L2, 16 replicas keep that to 60 per address
+            __syncthreads();
+            float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[(wave * 64 + lane) * 16 + q] = cs[q];
+            __syncthreads();
+            if (tid < 64) {
+                const int gg = tid >> 4, q = tid & 15;
+                float t = 0.f;
+                for (int w = 0; w < 4; ++w)
+                    for (int l = 0; l < 16; ++l) t += red[(w * 64 + gg * 16 + l) * 16 + q];
+                atomicAdd(p.skip_colsum + (blockIdx.x & 15) * 64 + tid, t);
+            }
         }
     }
 }
@@ -1078,16 +1109,18 @@ extern "C" int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_p
 // patch_embed's input gradient with the gradient merge at `feat` in its epilogue (training, H and W multiples of 8 so that the
 // reflect-padded map IS the map): out bf16 NHWC [B][H][W][64] = (gx Wt^T + add1 + add2) * (relu_src > 0) -- the three gradient paths
 // into `feat` (model.py:264 up branch, :268 patch_embed, :308 skip) and conv2's ReLU backward (model.py:252) without the separate
-// tup_feat_grad_combine pass over five 64-channel maps.  add2 may be NULL.
+// tup_feat_grad_combine pass over five 64-channel maps.  add2 may be NULL.  add1_colsum (optional, fp32 [16][64], zeroed by the caller)
+// += the per-channel sums of add1 in 16 replicas (the caller adds them up): add1 is the gradient entering patch_unembed's bias
+// (model.py:302-308), and every element of it passes through this kernel once anyway.
 extern "C" int tup_patch_embed_bwd_merge(const float* gx, const void* Wt, const void* add1, const void* add2, const void* relu_src,
-                                         void* out, int B, int H, int W, void* stream)
+                                         void* out, float* add1_colsum, int B, int H, int W, void* stream)
 {
     if (H % 8 || W % 8 || add1 == nullptr || relu_src == nullptr) return (int)hipErrorInvalidValue;
     GemmParams p{};
     p.Ht = H / 8; p.Wt_ = W / 8; p.H = H; p.W = W;
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = gx; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = out;
-    p.skip = (const bf16_t*)add1; p.skip2 = (const bf16_t*)add2; p.relu_src = (const bf16_t*)relu_src;
+    p.skip = (const bf16_t*)add1; p.skip2 = (const bf16_t*)add2; p.relu_src = (const bf16_t*)relu_src; p.skip_colsum = add1_colsum;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
     return launch_panel<A_F32, E_UNEMBED_MERGE>(p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -128,14 +128,17 @@ def branch_a_composed(x, wp, bias, wv, bv, r, relu=True):
 
 
 def conv_planar(x, w28, bias, r=1, add=None, clamp=False):
+    """clamp = "both" (training): returns (unclamped, clamped), written by the same kernel pass."""
     B, C, H, W = x.shape
     assert C == 3
     cout = 3 * r * r
-    out = torch.empty((B, 3, H * r, W * r), dtype=F32, device=x.device)
+    both = clamp == "both"
+    shape = (B, 3, H * r, W * r)
+    out = torch.empty(((2,) if both else ()) + shape, dtype=F32, device=x.device)
     _lib.call("tup_conv3x3_planar_fwd", _chk(x, F32, None, "x"), _chk(w28, F32, (cout, 28), "w28"),
-              _opt(bias, F32, (cout,), "bias"), _opt(add, F32, out.shape, "add"), out.data_ptr(),
-              B, H, W, r, int(clamp), _stream())
-    return out
+              _opt(bias, F32, (cout,), "bias"), _opt(add, F32, shape, "add"), out.data_ptr(),
+              B, H, W, r, 2 if both else int(bool(clamp)), _stream())
+    return (out[0], out[1]) if both else out
 
 
 _TAP_CACHE = {}
@@ -531,16 +534,18 @@ def patch_embed_bwd(gx, wt, B, H, W):
     return gmap
 
 
-def patch_embed_bwd_merge(gx, wt, add1, add2, relu_src):
-    """patch_embed's input gradient + the gradient merge at `feat` (feat_grad_combine) in one kernel; H, W multiples of 8."""
+def patch_embed_bwd_merge(gx, wt, add1, add2, relu_src, want_add1_colsum=False):
+    """patch_embed's input gradient + the gradient merge at `feat` (feat_grad_combine) in one kernel; H, W multiples of 8.
+    want_add1_colsum: also returns the fp32 [64] column sums of add1 (colsum(add1.view(-1, 64)) for free)."""
     B, H, W, C = relu_src.shape
     assert C == 64 and H % 8 == 0 and W % 8 == 0
     _, _, nwy, nwx = window_geometry(H, W)
     out = torch.empty_like(relu_src)
+    cs = _zeros((16, 64), relu_src.device) if want_add1_colsum else None
     _lib.call("tup_patch_embed_bwd_merge", _chk(gx, F32, (B * nwy * nwx * 64, 192), "gx"), _chk(wt, BF16, (4096, 192), "wt"),
               _chk(add1, BF16, relu_src.shape, "add1"), _opt(add2, BF16, relu_src.shape, "add2"), _chk(relu_src, BF16, None, "relu_src"),
-              out.data_ptr(), B, H, W, _stream())
-    return out
+              out.data_ptr(), cs.data_ptr() if want_add1_colsum else None, B, H, W, _stream())
+    return (out, cs.sum(0)) if want_add1_colsum else out
 
 
 def conv_c64_wgrad(x, gmap, gr=1):

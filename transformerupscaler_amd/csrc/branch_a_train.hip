@@ -349,23 +349,28 @@ __global__ __launch_bounds__(256, 2) void bra_wgrad_kernel(const bf16_t* __restr
                 for (int cit = 0; cit < 4; ++cit)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
+                        // (9.8 M float atomics per launch; without them the kernel takes the same 362 us: not its bound)
                         atomicAdd(G0 + (size_t)(blockIdx.x % REP) * GSZ + ((size_t)(4 * g + e) * NTAP + wave + 4 * a) * 64 + 16 * cit + l16, acc[a][cit][e]);
     }
 }
 
 // ---- weight gradient, ring part: G[v][n][t][ci] (v = 1..8) and Gb[v][n] from the HR ring pixels.  A workgroup owns a run of
 // RING_RUN ring pixels (thread = channel x tap group); partial sums per (variant-of-pixel, n, tap) go out as atomics -- the
-// run is cut so that all its pixels share one variant.  32-pixel runs: ~1,000 workgroups at 4 x 720p. ----
-constexpr int RING_RUN = 32;
+// run is cut so that all its pixels share one variant.  32-pixel runs, four pixels per trip: ~1,000 workgroups at 4 x 720p.  (Measured:
+// 128-pixel runs with eight pixels per trip -- a quarter of the atomics -- 492 us instead of 276: the serial length of a workgroup
+// weighs more than the atomics it saves.) ----
+constexpr int RING_RUN = 32, RING_PX = 4;
 __global__ __launch_bounds__(256) void bra_wgrad_ring_kernel(const float* __restrict__ g, const float* __restrict__ ui,
                                                              const bf16_t* __restrict__ x, float* __restrict__ G, float* __restrict__ Gb,
                                                              int B, int H, int W)
 {
     const int Hs = 2 * H, Ws = 2 * W;
     const int per_img = 2 * Ws + 2 * (Hs - 2);
-    const int ci = threadIdx.x & 63, tg = threadIdx.x >> 6;
+    // the tap group is the wave index (scalar): pixel coordinates, variants and tap addresses are wave-uniform; only `ci` is per lane.
+    // Timing split of the 276 us at 4 x 720p: 152 us without the flush atomics (10.7 M of them), i.e. 124 us of atomics.
+    const int ci = threadIdx.x & 63, tg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntap = (tg == 0) ? 7 : 6;
-    const long long k0 = (long long)blockIdx.x * RING_RUN;
+    const int k0 = blockIdx.x * RING_RUN, nring = per_img * B;          // (the host checks that the ring fits 31 bits)
     float acc[7][3];
     int cur_v = -1, cur_sp = -1;
     auto flush = [&]() {
@@ -378,19 +383,19 @@ __global__ __launch_bounds__(256) void bra_wgrad_ring_kernel(const float* __rest
                     atomicAdd(G + (size_t)(blockIdx.x % REP) * GSZ + (((size_t)cur_v * NOUT + c * 4 + cur_sp) * NTAP + tg + 4 * a) * 64 + ci, acc[a][c]);
     };
     // two passes over the run, one per sub-pixel phase parity along the run, so that (variant, phase) changes rarely; the pixels go
-    // four at a time with all their loads issued before the first use (one pixel per iteration paid a global round trip each)
+    // RING_PX at a time with all their loads issued before the first use (one pixel per iteration paid a global round trip each)
     for (int pass = 0; pass < 2; ++pass) {
-        for (int i0 = 0; i0 < RING_RUN; i0 += 4) {
-            int vv[4], spp[4];
-            float gv[4][3], f[4][7];
-            bool ok[4];
+        for (int i0 = 0; i0 < RING_RUN; i0 += RING_PX) {
+            int vv[RING_PX], spp[RING_PX];
+            float gv[RING_PX][3], f[RING_PX][7];
+            bool ok[RING_PX];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long long gid = k0 + i0 + j;
-                ok[j] = gid < (long long)per_img * B;
-                const int b = ok[j] ? (int)(gid / per_img) : 0;
+            for (int j = 0; j < RING_PX; ++j) {
+                const int gid = k0 + i0 + j;
+                ok[j] = gid < nring;
+                const int b = ok[j] ? gid / per_img : 0;
                 int Y, X;
-                ring_pixel(ok[j] ? (int)(gid - (long long)b * per_img) : 0, Hs, Ws, Y, X);
+                ring_pixel(ok[j] ? gid - b * per_img : 0, Hs, Ws, Y, X);
                 ok[j] = ok[j] && (((Y + X) & 1) == pass);
                 spp[j] = (Y & 1) * 2 + (X & 1);
                 vv[j] = variant_of(Y, X, Hs, Ws);
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void bra_wgrad_ring_kernel(const float* __rest
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < RING_PX; ++j) {
                 if (!ok[j]) continue;
                 if (vv[j] != cur_v || spp[j] != cur_sp) {
                     flush();
@@ -561,6 +566,7 @@ extern "C" int tup_bra_backward(const float* g, const float* ui, const void* fea
     bra_wgrad_kernel<<<dim3(persistent_blocks(nt)), dim3(256), WGRAD_LDS, s>>>((const bf16_t*)feat, (const bf16_t*)g12, G, B, H, W, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     const long long nring = (long long)B * (4LL * W + 2LL * (2 * H - 2));
+    if (nring > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     bra_wgrad_ring_kernel<<<dim3((unsigned)((nring + RING_RUN - 1) / RING_RUN)), dim3(256), 0, s>>>(g, ui, (const bf16_t*)feat, G, Gb, B, H, W);
     TUP_CHECK_LAUNCH();
     return 0;

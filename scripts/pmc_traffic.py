@@ -34,7 +34,8 @@ KEYS = {
         "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 2 * 192 * 2 + 576 * 2) + 960 * 12 * 64 * 4),      # qkv, d att, att, lse in; d qkv out
         "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 4 * F64),
         "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip", 2 * 4 * F64),
-        "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),
+        "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),          # only when H or W is not a multiple of 8
+        "pe_bwd_merge": ("gemm_panel2_kernel<1, 6>", "gemm_tokens.hip", 960 * 64 * 192 * 4 + 4 * 4 * F64),      # tokens in; two adds, the gate map in, the merged gradient out
     },
     "rt": {      # B = 2, ResidualTransformer 6x training step
         "rt_attn_fwd": ("rt_attention_kernel<true>", "rt_kernels.hip", 2 * 3600 * (384 + 128) * 2 + 2 * 8 * 3600 * 4),

@@ -298,6 +298,45 @@ def test_patch_embed_unembed_bwd(dev, hw):
     close(dwu, wu.grad, 3e-2, 2e-2, "patch_unembed dW")
 
 
+@pytest.mark.parametrize("hw,two", [((64, 64), True), ((24, 40), False), ((72, 128), True)])
+def test_patch_embed_bwd_merge_equals_separate_passes(dev, hw, two):
+    """tup_patch_embed_bwd_merge (patch_embed's input gradient with the gradient merge at `feat` + conv2's ReLU gate in its epilogue,
+    and the column sums of add1 riding along) against the three separate passes it replaces: tup_patch_embed_bwd,
+    tup_feat_grad_combine, tup_colsum.  The merged form keeps the GEMM value in fp32 where the separate one read it back as bf16."""
+    from transformerupscaler_amd import ops, packing
+    H, W = hw
+    B = 2
+    _, _, nwy, nwx = ops.window_geometry(H, W)
+    gx = rnd((B * nwy * nwx * 64, 192), 81).to(dev)
+    w = bf(rnd((192, 64, 8, 8), 82, 0.02))
+    wt_bwd = packing.pack_linear(w.permute(2, 3, 1, 0).reshape(4096, 192)).to(dev)
+    add1 = rnd((B, H, W, 64), 83).to(torch.bfloat16).to(dev)
+    add2 = rnd((B, H, W, 64), 84).to(torch.bfloat16).to(dev) if two else None
+    feat = rnd((B, H, W, 64), 85).to(torch.bfloat16).to(dev)          # about half of it <= 0: the ReLU gate
+    ref = ops.feat_grad_combine(add1, add2, ops.patch_embed_bwd(gx, wt_bwd, B, H, W), feat).float()
+    got, cs = ops.patch_embed_bwd_merge(gx, wt_bwd, add1, add2, feat, want_add1_colsum=True)
+    assert torch.equal(got == 0, ref == 0) or ((got == 0) != (ref == 0)).float().mean().item() < 1e-3      # same gate
+    close(got, ref, 2e-2, 1e-2, "merged gradient at feat")
+    close(cs, ops.colsum(add1.view(-1, 64)), 5e-2, 2e-3, "column sums of add1")
+    got2 = ops.patch_embed_bwd_merge(gx, wt_bwd, add1, add2, feat)
+    assert torch.equal(got2, got)
+
+
+def test_planar_conv_and_resize_write_gate_and_clamped_output_together(dev):
+    """clamp01 = 2 of tup_conv3x3_planar_fwd / tup_resize_aa_fwd (training): [unclamped | clamped] from one pass == the two separate calls."""
+    from transformerupscaler_amd import ops, packing
+    x = (rnd((2, 3, 36, 48), 86) * 1.5 + 0.5).to(dev)
+    w, b = rnd((3, 3, 3, 3), 87, 0.4), rnd((3,), 88, 0.2)
+    w28 = packing.pack_planar(w).to(dev)
+    add = rnd((2, 3, 36, 48), 89).to(dev)
+    pre, out = ops.conv_planar(x, w28, b.to(dev), 1, add=add, clamp="both")
+    assert torch.equal(pre, ops.conv_planar(x, w28, b.to(dev), 1, add=add, clamp=False))
+    assert torch.equal(out, ops.conv_planar(x, w28, b.to(dev), 1, add=add, clamp=True))
+    assert (out != pre).float().mean().item() > 0.05          # the clamp did something
+    pre2, out2 = ops.resize_aa(x, (27, 36), clamp="both")
+    assert torch.equal(pre2, ops.resize_aa(x, (27, 36), clamp=False)) and torch.equal(out2, ops.resize_aa(x, (27, 36), clamp=True))
+
+
 # ------------------------------------------------------------------------------------------------
 # conv-side backward kernels
 # ------------------------------------------------------------------------------------------------

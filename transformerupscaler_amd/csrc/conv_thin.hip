@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
     }
 }
 
+#ifndef TUP_CONV1_OCC
+#define TUP_CONV1_OCC 4
+#endif
 // Persistent form of the kernel above: a workgroup walks tiles blockIdx.x, + gridDim.x, ... .  conv1 is a 943 MB store
 // stream (128 B written per pixel against 12 B read) and the one-tile kernel pays a global round trip (halo loads ->
 // LDS) in front of every 32 KB of stores: 2.7 TB/s written.  Here the halo values are requested into registers TWO
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
 // up once per workgroup and the (element -> source offset) map of the staging once per thread: 3.2 TB/s (353 -> 295 us
 // at 8 x 720p).  What is left is the interaction of the scattered fp32 halo reads with the store stream: without the
 // reads the same kernel stores at 4.8 TB/s (timing ablation), and a dedicated loader wave did not beat this form.
-__global__ __launch_bounds__(256) void conv3x3_c3_persistent_kernel(
+__global__ __launch_bounds__(256, TUP_CONV1_OCC) void conv3x3_c3_persistent_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_mask, const bf16_t* __restrict__ out_mask,
     bf16_t* __restrict__ out, int H, int W, int relu, int tilesX, int tilesY, int ntiles)
@@ -504,7 +507,8 @@ extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* b
     if (!one_tile && (long long)B * 3 * H * W < (1LL << 31)) {
         // three workgroups are resident per CU (140 registers): grids of 3, 6 or 12 per CU run the same 282-285 us at 8 x 720p, 2 or 4
         // per CU (a partial round) 330 us
-        const unsigned grid = (unsigned)(nblk < 256 * 6 ? nblk : 256 * 6);
+        static const int per_cu = [] { const char* e = getenv("TUP_CONV1_WG_PER_CU"); return e ? atoi(e) : 2 * TUP_CONV1_OCC; }();
+        const unsigned grid = (unsigned)(nblk < 256 * per_cu ? nblk : 256 * per_cu);
         conv3x3_c3_persistent_kernel<<<dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
             x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY, (int)nblk);
         TUP_CHECK_LAUNCH();

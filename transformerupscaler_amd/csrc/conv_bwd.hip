@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_c3_kernel(
 // tile in flight under the previous tile's arithmetic); RT = 0: generic r, staged in place (a load -> LDS-store loop with
 // run-time bounds is not unrolled and pays a global round trip per iteration: 20 us per 1,024-pixel tile, the whole 0.36 ms).
 template <int RT, int THT>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_planar_kernel(
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_planar_kernel(
     const float* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dw, float* __restrict__ dbias,
     int B, int H, int W, int r_, int th_, int tilesX, int tilesY)
 {
@@ -895,9 +895,10 @@ extern "C" int tup_conv3x3_planar_wgrad(const float* x, const float* gpl, float*
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const size_t lds = ((size_t)3 * (th + 2) * HALO_W + (size_t)cout * th * 32 + (size_t)r * r * 84) * sizeof(float);
-    // persistent workgroups, one resident set: the r = 2 instance holds 132 registers = three workgroups per CU (four were 1,024
-    // workgroups on 768 slots: 1.33 rounds, scripts/grid_rounds.py), the others four
-    const dim3 grid(persistent_grid(nt, r == 2 ? 3 : 4));
+    // persistent workgroups, one resident set.  The r = 1 and r = 2 instances hold 239 / 256 registers = TWO workgroups per CU (the r = 2
+    // one compiled to 258 without the bound above: ONE workgroup per CU, and its grid of three or four per CU ran as three or four
+    // rounds); the generic instance (118 registers) four
+    const dim3 grid(persistent_grid(nt, r <= 2 ? 2 : 4));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (r == 1) conv3x3_wgrad_planar_kernel<1, 32><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);
     else if (r == 2) conv3x3_wgrad_planar_kernel<2, 16><<<grid, dim3(256), lds, st>>>(x, gpl, dw, dbias, B, H, W, r, th, tilesX, tilesY);

@@ -23,6 +23,8 @@ TUP_DEVICE bf16x8 join4(s16x4 lo, s16x4 hi) {
 constexpr int RD = 128, RH = 8, HD = 16;
 
 // ---- flash-style attention, one wave per (batch, head, 64-query tile); S^T tiles in registers, online softmax ----
+// (151 registers = three workgroups per CU: the 912 workgroups of a B = 2 step are 1.19 rounds.  Bounded to four per CU -- 1,024 slots,
+// one round -- the kernel spills 13 registers and is slower, 138 vs 130 us.)
 template <bool DROP>
 __global__ __launch_bounds__(256) void rt_attention_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int B, int N, int qtiles,

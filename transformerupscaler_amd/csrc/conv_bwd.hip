@@ -559,7 +559,9 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_planar_kernel(
 // The 6 HR rows x 12 HR columns the four pixels gather from are four aligned 16-byte loads per row (72 loads per thread instead
 // of 432 two-element-strided ones); every HR value feeds up to three of the four outputs, all with wave-uniform weights (scalar
 // loads from the weight tensor: the indices are compile-time constants).  W % 4 == 0.
-__global__ __launch_bounds__(256) void conv3x3_dgrad_planar_r2x4_kernel(
+// (bounded to two waves per SIMD: unbounded it took 305 registers = ONE wave per SIMD for a streaming kernel, 218 us; with the bound 255
+// registers and 8 spilled ones, 142 us)
+__global__ __launch_bounds__(256, 2) void conv3x3_dgrad_planar_r2x4_kernel(
     const float* __restrict__ gpl, const float* __restrict__ w, float* __restrict__ gx, int H, int W)
 {
     const int ox = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;

@@ -760,7 +760,7 @@ def test_blocks_one_window_per_workgroup_equals_two(dev):
     assert torch.equal(sm, big[:small * 64])
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 8, 32), (1, 13, 37), (2, 24, 70), (1, 6, 6)])
+@pytest.mark.parametrize("B,H,W", [(2, 8, 32), (1, 13, 37), (2, 24, 70), (1, 6, 6), (1, 9, 113), (3, 19, 28)])
 def test_branch_a_composed_training(dev, B, H, W):
     """csrc/branch_a_train.hip: forward of the composed branch A and its whole backward (input gradient incl. the ring, the
     gradient w.r.t. the composed weights, the chain rule to W_up / b_up / W_3) against torch autograd through the explicit

@@ -577,6 +577,239 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Composed branch A at r = 2 (12 outputs) as a ROW GEMM.  The 25-tap form above (CT = 1, KS = 5) reads four pixel fragments
+// and one weight fragment from LDS for every four MFMAs -- each halo pixel 25 times -- and runs exactly at the LDS read rate
+// (1 MB per tile, 8 k cycles against 3.2 k of MFMA issue).  Here the five horizontal taps ride in the GEMM's N instead:
+//     part[y][x'][(c, dx)] = sum_dy sum_ci  in[y + dy][x'][ci] * w[dy][dx][c][ci]          K = 5 * 64, N = 60 (64 rows)
+//     out[y][x][c]         = sum_dx part[y][x + dx][(c, dx)]
+// so a halo pixel is read five times (once per dy) and a K-step is 4 pixel + 4 weight fragments for 16 MFMAs.  The weight
+// rows are ordered so that lane (g, p) of the accumulators ends with sub-pixel g's three image channels x five dx (slot
+// s = tile*4 + e = ch*5 + dx) of halo column p: the dx sum is 4 + 4 DPP row shifts per output, no LDS round trip.
+// Tile = 8 rows x 28 output columns (halo image 12 x 32 pixels: two whole 16-pixel groups per row); the ping-pong / DMA
+// skeleton is the persistent kernel's.  LDS: 5*8 KB + 2*48 KB = 139,264 B.
+// ------------------------------------------------------------------------------------------------
+constexpr int R5_TW = 28, R5_HW = 32, R5_HH = TH + 4, R5_NPIX = R5_HH * R5_HW, R5_IN_BYTES = R5_NPIX * 128;
+constexpr int R5_W_BYTES = 5 * 64 * 128;
+
+__global__ __launch_bounds__(512, 2) void bra_rows_persistent_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int B, int H, int W, int relu, int tilesX, int tilesY, int ablate)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w_lds = smem;                              // [5 dy][64 rows][128 B]
+    char* in_lds = smem + R5_W_BYTES;                // [2 groups][R5_IN_BYTES]
+    const int grp = threadIdx.x >> 8;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    const int total_tiles = tilesX * tilesY * B;
+    char* my_in = in_lds + grp * R5_IN_BYTES;
+
+    constexpr int IN_CHUNKS = R5_NPIX * 8, NPIECE = IN_CHUNKS / 256;          // 12 pieces exactly
+    static_assert(IN_CHUNKS % 256 == 0, "whole DMA pieces");
+    int rel[NPIECE];
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
+        const int idx = it * 256 + tid;
+        const int q = idx >> 3, c = (idx & 7) ^ ((q >> 1) & 7);
+        const int yy = q / R5_HW, xx = q - yy * R5_HW;
+        rel[it] = ((yy - 2) * W + (xx - 2)) * 128 + c * 16;
+    }
+    auto prefetch_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * R5_TW;
+        const char* xb = reinterpret_cast<const char*>(x + (size_t)b * H * W * 64);
+        if (ty0 >= 2 && ty0 + TH + 2 <= H && tx0 >= 2 && tx0 + R5_HW - 2 <= W) {          // interior tile
+            const char* tb = xb + ((size_t)ty0 * W + tx0) * 128;
+#pragma unroll
+            for (int it = 0; it < NPIECE; ++it)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + rel[it]),
+                                                 (__attribute__((address_space(3))) void*)(my_in + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            return;
+        }
+#pragma unroll 1
+        for (int base = 0; base < IN_CHUNKS; base += 256) {
+            const int idx = base + tid;
+            const int q = idx >> 3, c = (idx & 7) ^ ((q >> 1) & 7);
+            const int yy = q / R5_HW, xx = q - yy * R5_HW;
+            const int iy = ty0 - 2 + yy, ix = tx0 - 2 + xx;
+            const void* src = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                  ? (const void*)(xb + ((size_t)(iy * W + ix) * 128 + c * 16)) : (const void*)tup_zero_line;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(my_in + (base + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // weights: LDS row (dy, tile t, r = 4*gg + e) <- tap (dy, dx), output co = ch*4 + gg of the 25-tap packing [25][16][64],
+    // slot s = t*4 + e = ch*5 + dx (slot 15 is zero)
+    for (int idx = threadIdx.x; idx < 5 * 64 * 8; idx += 512) {
+        const int row = idx >> 3, c = idx & 7;
+        const int dy = row >> 6, t = (row >> 4) & 3, r16 = row & 15;
+        const int gg = r16 >> 2, sl = t * 4 + (r16 & 3);
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (sl < 15) {
+            const int ch = sl / 5, dx = sl - ch * 5;
+            v = *reinterpret_cast<const u32x4*>(wp + ((size_t)((dy * 5 + dx) * 16 + ch * 4 + gg)) * 64 + c * 8);
+        }
+        *reinterpret_cast<u32x4*>(w_lds + swz128(row, c)) = v;
+    }
+    float bch[3];                                    // this lane's sub-pixel g, channels 0..2
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) bch[ch] = bias ? bias[ch * 4 + g] : 0.f;
+
+    // fragment addresses: the swizzle phase ((q >> 1) & 7) of pixel q = row*32 + cg*16 + p and of weight row dy*64 + t*16 + p
+    // is (p >> 1) & 7 for both, so one base register each and everything else in the 16-bit immediate
+    const uint32_t pbase = lds_addr(my_in) + (uint32_t)(2 * wave * R5_HW * 128) + (uint32_t)swz128(p, g);
+    const uint32_t wbase = lds_addr(w_lds) + (uint32_t)swz128(p, g);
+
+    f32x4 acc[2][2][4];                              // [output row of the wave][16-column group][weight tile]
+    // K loop: 10 steps (dy, K half) of 8 fragments + 16 MFMAs, fragments requested two steps ahead (3-slot ring).  The requests
+    // of step + 2 are placed one after every second MFMA of the step: issued in a block at the top of the step they cost the
+    // wave ~60 cycles per step in which its matrix pipe idles, and with one wave per SIMD in a K loop nothing else fills it.
+    auto compute_tile = [&]() {
+        constexpr int NSTEPS = 10;
+        bf16x8 pf[3][4], wf[3][4];
+        auto load_frag = [&](int step, int slot, int j) {          // j = 0..3 pixel fragments (rw*2 + cg), 4..7 weight tiles
+            const int dy = step >> 1;
+            if (j < 4) {
+                const int off = ((j >> 1) + dy) * (R5_HW * 128) + (j & 1) * 2048;
+                pf[slot][j] = (step & 1) ? lds_read_b128_asm_off_x64(pbase, off) : lds_read_b128_asm_off(pbase, off);
+            } else {
+                const int off = dy * 8192 + (j - 4) * 2048;
+                wf[slot][j - 4] = (step & 1) ? lds_read_b128_asm_off_x64(wbase, off) : lds_read_b128_asm_off(wbase, off);
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_frag(0, 0, j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) load_frag(1, 1, j);
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw)
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[rw][cg][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int step = 0; step < NSTEPS; ++step) {
+            const int cur = step % 3;
+            if (step + 1 < NSTEPS) lds_wait<8>(); else lds_wait<0>();       // this step's fragments; the next step's may still fly
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (step + 2 < NSTEPS) load_frag(step + 2, (step + 2) % 3, j);
+                // MFMA pair j: pixel fragment i = j >> 1, weight tiles 2*(j & 1), +1
+                const int i = j >> 1, t0 = (j & 1) * 2;
+                acc[i >> 1][i & 1][t0] = mfma16x16x32(wf[cur][t0], pf[cur][i], acc[i >> 1][i & 1][t0]);
+                acc[i >> 1][i & 1][t0 + 1] = mfma16x16x32(wf[cur][t0 + 1], pf[cur][i], acc[i >> 1][i & 1][t0 + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // acc += (v of lane p + n of the same 16-lane row, 0 past its end) / (v of lane p - n, 0 before its start): one
+    // v_add_f32 with a DPP source (hipcc keeps a v_mov_b32_dpp + v_add_f32 pair per term: 154 instead of 82 instructions, and
+    // every VALU instruction of this phase takes issue cycles from the other group's MFMA stream on the same SIMD)
+#define TUP_ADD_DPP(acc, v, ctrl) asm("v_add_f32_dpp %0, %1, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v))
+    auto store_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int Wr = W * 2, si = g >> 1, sj = g & 1;
+        const int plane = 4 * H * W;                 // elements of one HR plane
+        float* outb = out + (size_t)b * 3 * plane;
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            const int oy = ty * TH + 2 * wave + rw;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                const int xo = cg * 16 + p, ox = tx * R5_TW + xo;
+                const bool ok = oy < H && ox < W && xo < R5_TW;
+                // exactly 12 store instructions per wave and tile (the counted wait of the phase loop): lanes outside the tile /
+                // image go to the sink
+                float* o = ok ? outb + ((oy * 2 + si) * Wr + (ox * 2 + sj)) : reinterpret_cast<float*>(tup_store_sink) + lane;
+                const int pstep = ok ? plane : 0;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    auto part = [&](int c2, int dx) { const int sl = ch * 5 + dx; return acc[rw][c2][sl >> 2][sl & 3]; };
+                    float v = part(cg, 0) + bch[ch];
+                    TUP_ADD_DPP(v, part(cg, 1), "row_shl:1"); TUP_ADD_DPP(v, part(cg, 2), "row_shl:2");
+                    TUP_ADD_DPP(v, part(cg, 3), "row_shl:3"); TUP_ADD_DPP(v, part(cg, 4), "row_shl:4");
+                    if (cg == 0) {                   // halo columns 16..19 live in the next group's lanes 0..3
+                        TUP_ADD_DPP(v, part(1, 1), "row_shr:15"); TUP_ADD_DPP(v, part(1, 2), "row_shr:14");
+                        TUP_ADD_DPP(v, part(1, 3), "row_shr:13"); TUP_ADD_DPP(v, part(1, 4), "row_shr:12");
+                    }
+                    if (relu) v = fmaxf(v, 0.f);
+                    o[ch * pstep] = v;
+                }
+            }
+        }
+    };
+#undef TUP_ADD_DPP
+
+    // Tiles of this workgroup.  Workgroups go to the eight XCDs round-robin (blockIdx & 7), each with its own L2: an XCD takes
+    // one contiguous eighth of the tile list and its 32 workgroups walk it side by side, so the halo a tile shares with its
+    // left / right neighbours (same moment) and with the tile row above (46 tiles earlier) is found in THAT L2 instead of
+    // crossing the fabric once per XCD (halo image / tile = 1.71: the DMA alone ran at the same 227 us with nothing else on).
+    int first, first0, stride, limit;
+    if ((gridDim.x & 7) == 0 && !(ablate & 8)) {
+        const int per = gridDim.x >> 3, band = (total_tiles + 7) >> 3, start = (blockIdx.x & 7) * band;
+        limit = min(total_tiles, start + band);
+        first0 = start + (blockIdx.x >> 3);
+        first = first0 + grp * per;
+        stride = 2 * per;
+    } else {
+        limit = total_tiles;
+        first0 = blockIdx.x;
+        first = first0 + grp * gridDim.x;
+        stride = 2 * gridDim.x;
+    }
+    const int my_count = first < limit ? (limit - first + stride - 1) / stride : 0;
+    const int cnt0 = first0 < limit ? (limit - first0 + stride - 1) / stride : 0;      // group 0's count >= group 1's
+    const int nphases = 2 * cnt0 + 1;               // uniform for the whole workgroup
+
+    if (grp == 0 && my_count > 0) prefetch_tile(first);
+    __syncthreads();
+    for (int ph = 0; ph < nphases; ++ph) {
+        const int k = ph >> 1;
+        if ((ph & 1) == grp) {
+            if (k < my_count && !(ablate & 1)) compute_tile();
+        } else {
+            const int done = grp == 0 ? k : k - 1;
+            const int nxt = done + 1;
+            if (nxt < my_count && !(ablate & 4)) prefetch_tile(first + nxt * stride);
+            if (done >= 0 && done < my_count && !(ablate & 2)) {
+                store_tile(first + done * stride);
+                // the DMA (issued first) must have landed before the barrier, the 12 stores after it need not
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int launch_bra_rows(const void* x, const void* wp, const float* bias, float* out, int B, int H, int W, int relu, hipStream_t s)
+{
+    constexpr size_t lds = (size_t)R5_W_BYTES + 2 * (size_t)R5_IN_BYTES;
+    static_assert(lds <= 163840, "LDS budget");
+    TUP_SET_DYN_LDS(bra_rows_persistent_kernel, lds);
+    const int tilesX = (W + R5_TW - 1) / R5_TW, tilesY = (H + TH - 1) / TH;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
+    static const int ablate = getenv("TUP_BRA_ABLATE") ? atoi(getenv("TUP_BRA_ABLATE")) : 0;     // timing experiments: 1 no K loop, 2 no stores, 4 no DMA
+    bra_rows_persistent_kernel<<<dim3(grid), dim3(512), lds, s>>>((const bf16_t*)x, (const bf16_t*)wp, bias, out, B, H, W, relu, tilesX, tilesY, ablate);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
 // Border fix-up of the composed branch-A conv (see tup_conv5x5_c64_planar_fwd): one wave per HR border
 // pixel recomputes it with the weight variant that leaves out the 64->3 conv's taps falling outside
 // the HR image (those see zero padding in the reference, not a virtual up-conv value).
@@ -710,8 +943,10 @@ extern "C" int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const f
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nout = 3 * r * r;
     static const bool use_persistent5 = (getenv("TUP_CONV_NONPERSISTENT") == nullptr);
+    static const bool use_taps25 = (getenv("TUP_BRA_TAPS25") != nullptr);       // A/B: the 25-tap form of round 1-2
     if (r == 2 && use_persistent5) {
-        int e = launch_persistent<1, OUT_PLANAR_F32, 5>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, r, nout, relu, s);
+        int e = use_taps25 ? launch_persistent<1, OUT_PLANAR_F32, 5>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, r, nout, relu, s)
+                           : launch_bra_rows(x, wp, bias, out, B, H, W, relu, s);
         if (e) return e;
     } else if (r == 2) {
         conv3x3_c64_kernel<1, OUT_PLANAR_F32, 5><<<dim3((unsigned)nblk), dim3(256), in_tile_bytes(5) + 2 * 16 * 128, s>>>(

@@ -21,7 +21,7 @@ import sys
 GUARDED = [
     ("fused_attn.hip", ["fused_qkv_attn_kernel"]),
     ("fused_blocks.hip", ["fused_mlp_v2_kernel"]),
-    ("conv3x3_c64.hip", ["conv_c64_persistent_kernel", "bra_rows_persistent_kernel"]),
+    ("conv3x3_c64.hip", ["conv_c64_persistent_kernel", "bra_rows_persistent_kernel", "conv3_thin_rows_kernel"]),
     ("conv_thin.hip", ["conv3x3_c3_persistent_kernel"]),
     ("gemm_tokens.hip", ["gemm_panel2_kernel", "patch_embed_kernel"]),
 ]

@@ -810,6 +810,159 @@ int launch_bra_rows(const void* x, const void* wp, const float* bias, float* out
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 64 -> (<= 4) channel 3x3 conv with planar fp32 output (decoder_conv2; up1_conv in training) as a row GEMM: N = (channel c,
+// dx) = weight row 4c + dx, K = 3 dy x 64, so a halo pixel is read from LDS three times, a wave's whole K loop is 24 MFMAs with
+// the six weight fragments in registers, and out[x][c] = part[c][0](x) + part[c][1](x + 1) + part[c][2](x + 2) is two DPP row
+// shifts.  The kernel is HBM-class (reads 128 B per pixel, writes 12): the ping-pong form above keeps ONE 43.5 KB tile in flight
+// per CU and its phases were the DMA latency (3.9 TB/s).  Here a workgroup is 4 waves with one 40 KB halo image (8 x 28 output
+// pixels, halo 10 x 32), THREE workgroups per CU each walking its own tiles: three images in flight per CU, no counted waits.
+// ------------------------------------------------------------------------------------------------
+constexpr int T3_TW = 28, T3_HW = 32, T3_HH = TH + 2, T3_NPIX = T3_HH * T3_HW, T3_IN_BYTES = T3_NPIX * 128;
+
+__global__ __launch_bounds__(256, 3) void conv3_thin_rows_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ out, int B, int H, int W, int cout, int relu, int tilesX, int tilesY)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];              // one halo image
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    const int total_tiles = tilesX * tilesY * B;
+
+    constexpr int IN_CHUNKS = T3_NPIX * 8, NPIECE = IN_CHUNKS / 256;         // 10 pieces exactly
+    static_assert(IN_CHUNKS % 256 == 0, "whole DMA pieces");
+    int rel[NPIECE];
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
+        const int idx = it * 256 + tid;
+        const int q = idx >> 3, c = (idx & 7) ^ ((q >> 1) & 7);
+        const int yy = q / T3_HW, xx = q - yy * T3_HW;
+        rel[it] = ((yy - 1) * W + (xx - 1)) * 128 + c * 16;
+    }
+    auto prefetch_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        const int ty0 = ty * TH, tx0 = tx * T3_TW;
+        const char* xb = reinterpret_cast<const char*>(x + (size_t)b * H * W * 64);
+        if (ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + T3_HW - 1 <= W) {          // interior tile
+            const char* tb = xb + ((size_t)ty0 * W + tx0) * 128;
+#pragma unroll
+            for (int it = 0; it < NPIECE; ++it)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + rel[it]),
+                                                 (__attribute__((address_space(3))) void*)(smem + (it * 256 + wave * 64) * 16), 16, 0, 0);
+            return;
+        }
+#pragma unroll 1
+        for (int base = 0; base < IN_CHUNKS; base += 256) {
+            const int idx = base + tid;
+            const int q = idx >> 3, c = (idx & 7) ^ ((q >> 1) & 7);
+            const int yy = q / T3_HW, xx = q - yy * T3_HW;
+            const int iy = ty0 - 1 + yy, ix = tx0 - 1 + xx;
+            const void* src = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                  ? (const void*)(xb + ((size_t)(iy * W + ix) * 128 + c * 16)) : (const void*)tup_zero_line;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + (base + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+
+    // weight fragments (A operand: lane (g, p) = row p = 4c + dx, channels 8g.. of K half kh) straight from the packed
+    // [9 taps][16 rows][64] tensor (row = output channel): six 16-byte loads per lane, once
+    bf16x8 wfr[3][2];
+    {
+        const int c = p >> 2, dx = p & 3;
+        const bool live = dx < 3 && c < cout;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                u32x4 v = u32x4{0u, 0u, 0u, 0u};
+                if (live) v = *reinterpret_cast<const u32x4*>(wp + ((size_t)((dy * 3 + dx) * 16 + c)) * 64 + kh * 32 + g * 8);
+                wfr[dy][kh] = __builtin_bit_cast(bf16x8, v);
+            }
+    }
+    const float bv = (bias && g < cout) ? bias[g] : 0.f;       // the accumulators' lane (g, p) = channel g
+    const uint32_t pbase = lds_addr(smem) + (uint32_t)(2 * wave * T3_HW * 128) + (uint32_t)swz128(p, g);
+
+    f32x4 acc[2][2];                                 // [output row of the wave][16-column group]
+    auto compute_tile = [&]() {
+        bf16x8 pf[6][4];
+#pragma unroll
+        for (int st = 0; st < 6; ++st)               // st = dy*2 + kh
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {            // i = rw*2 + cg
+                const int off = ((i >> 1) + (st >> 1)) * (T3_HW * 128) + (i & 1) * 2048;
+                pf[st][i] = (st & 1) ? lds_read_b128_asm_off_x64(pbase, off) : lds_read_b128_asm_off(pbase, off);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            if (st == 0) lds_wait<15>(); else if (st == 1) lds_wait<15>(); else if (st == 2) lds_wait<12>();
+            else if (st == 3) lds_wait<8>(); else if (st == 4) lds_wait<4>(); else lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = mfma16x16x32(wfr[st >> 1][st & 1], pf[st][i], acc[i >> 1][i & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#define TUP_ADD_DPP(a, v, ctrl) asm("v_add_f32_dpp %0, %1, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a) : "v"(v))
+    auto store_tile = [&](int tile) {
+        int t = tile;
+        const int tx = t % tilesX; t /= tilesX;
+        const int ty = t % tilesY;
+        const int b = t / tilesY;
+        float* outb = out + ((size_t)b * cout + g) * H * W;
+#pragma unroll
+        for (int rw = 0; rw < 2; ++rw) {
+            const int oy = ty * TH + 2 * wave + rw;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                const int xo = cg * 16 + p, ox = tx * T3_TW + xo;
+                float v = acc[rw][cg][0] + bv;
+                TUP_ADD_DPP(v, acc[rw][cg][1], "row_shl:1"); TUP_ADD_DPP(v, acc[rw][cg][2], "row_shl:2");
+                if (cg == 0) { TUP_ADD_DPP(v, acc[rw][1][1], "row_shr:15"); TUP_ADD_DPP(v, acc[rw][1][2], "row_shr:14"); }
+                if (relu) v = fmaxf(v, 0.f);
+                if (g < cout && oy < H && ox < W && xo < T3_TW) outb[(size_t)oy * W + ox] = v;
+            }
+        }
+    };
+#undef TUP_ADD_DPP
+
+    // tiles: XCD-contiguous bands as in bra_rows_persistent_kernel (blockIdx & 7 = XCD)
+    int first, stride, limit;
+    if ((gridDim.x & 7) == 0) {
+        const int per = gridDim.x >> 3, band = (total_tiles + 7) >> 3, start = (blockIdx.x & 7) * band;
+        limit = min(total_tiles, start + band);
+        first = start + (blockIdx.x >> 3);
+        stride = per;
+    } else {
+        limit = total_tiles; first = blockIdx.x; stride = gridDim.x;
+    }
+    if (first < limit) prefetch_tile(first);
+    for (int tile = first; tile < limit; tile += stride) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // the image of `tile` is complete
+        compute_tile();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // everyone's fragment reads are done: the image may be overwritten
+        if (tile + stride < limit) prefetch_tile(tile + stride);
+        store_tile(tile);                            // under the next image's flight
+    }
+}
+
+int launch_thin_rows(const void* x, const void* wp, const float* bias, float* out, int B, int H, int W, int cout, int relu, hipStream_t s)
+{
+    const int tilesX = (W + T3_TW - 1) / T3_TW, tilesY = (H + TH - 1) / TH;
+    const long long nt = (long long)tilesX * tilesY * B;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const int grid = (int)(nt < 768 ? nt : 768);                 // three workgroups per CU
+    conv3_thin_rows_kernel<<<dim3(grid), dim3(256), T3_IN_BYTES, s>>>((const bf16_t*)x, (const bf16_t*)wp, bias, out, B, H, W, cout, relu, tilesX, tilesY);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
 // Border fix-up of the composed branch-A conv (see tup_conv5x5_c64_planar_fwd): one wave per HR border
 // pixel recomputes it with the weight variant that leaves out the 64->3 conv's taps falling outside
 // the HR image (those see zero padding in the reference, not a virtual up-conv value).
@@ -897,6 +1050,8 @@ extern "C" int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* b
         }
         if (out_mode == OUT_PLANAR_F32) {
             if (ntiles != 1 || r != 1 || cout_valid < 1 || cout_valid > 16 || add || mask) return (int)hipErrorInvalidValue;
+            static const bool thin_pingpong = (getenv("TUP_THIN_PINGPONG") != nullptr);      // A/B: the round 1-2 form
+            if (cout_valid <= 4 && !thin_pingpong) return launch_thin_rows(x, wp, bias, (float*)out, B, H, W, cout_valid, relu, s);
             return launch_persistent<1, OUT_PLANAR_F32, 3>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, 1, cout_valid, relu, s);
         }
         return (int)hipErrorInvalidValue;

@@ -97,6 +97,19 @@ def test_composed_branch_a_matches_explicit(model, det_sd, scale, shape):
     assert (got_c - ref).abs().mean().item() <= (got_e - ref).abs().mean().item() * 1.1 + 1e-5
 
 
+def test_packed_weights_are_kept_per_scale(model):
+    """Alternating-scale inference re-packs nothing while the parameters are unchanged (one cache entry);
+    a parameter update drops every entry."""
+    with torch.no_grad():
+        pk2 = model.packed(2)[0]
+        pk4 = model.packed(4)[0]
+        assert model.packed(2)[0] is pk2 and model.packed(4)[0] is pk4
+        p = next(model.parameters())
+        p.add_(0.0)                                  # in-place write: version counter moves
+        assert model.packed(2)[0] is not pk2
+        assert len(model._pack_cache) == 1
+
+
 def test_unbuilt_scale_and_cpu_inputs_raise(model):
     with pytest.raises(ValueError):
         model(torch.rand(1, 3, 16, 16).cuda(), res_out=(80, 80))

@@ -364,7 +364,6 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
             for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = acc[0][ct];      // bias rides in the accumulator
         constexpr int NSTEPS = NTAPS * 2;
         constexpr int PER = 4 + CT;                                         // ds_reads per K-step
-        constexpr int W1 = PER * 2 > 15 ? 15 : PER * 2;                     // lgkmcnt is a 4-bit field
         bf16x8 pf[3][4], wf[3][CT];
         auto load_frags = [&](int step, int slot) {
             const int tap = step >> 1;
@@ -381,18 +380,38 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         };
         load_frags(0, 0);
         load_frags(1, 1);
+        // the requests of step + 2 are spread over the step's MFMAs (one per NM / PER of them): issued as a block at the top
+        // of the step they cost the wave ~60 issue cycles per step in which its matrix pipe idles (conv2: 450 -> 425 us)
+        auto load_one = [&](int step, int slot, int j) {
+            const int tap = step >> 1;
+            if (j < 4) {
+                pf[slot][j] = (step & 1) ? lds_read_b128_asm_off_x64(poff[tap][j >> 1], (j & 1) * 2048)
+                                         : lds_read_b128_asm_off(poff[tap][j >> 1], (j & 1) * 2048);
+            } else {
+                const int ct = j - 4;
+                const int woff = (tap * WROWS + ct * 16) * 128;
+                wf[slot][ct] = woff < 57344 ? lds_read_b128_asm_off((step & 1) ? wbase1 : wbase0, woff)
+                                            : lds_read_b128_asm_off((step & 1) ? wbase1h : wbase0h, woff - 57344);
+            }
+        };
 #pragma unroll
         for (int step = 0; step < NSTEPS; ++step) {
             const int cur = step % 3;
-            if (step + 2 < NSTEPS) { load_frags(step + 2, (step + 2) % 3); lds_wait<W1>(); }
-            else if (step + 1 < NSTEPS) { lds_wait<PER>(); }
-            else { lds_wait<0>(); }
+            if (step + 1 < NSTEPS) lds_wait<PER>(); else lds_wait<0>();
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int NM = 4 * CT;
+            int rd = 0;
 #pragma unroll
-            for (int pg = 0; pg < 4; ++pg)
+            for (int m = 0; m < NM; ++m) {
+                if (step + 2 < NSTEPS) {
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[pg][ct] = mfma16x16x32(wf[cur][ct], pf[cur][pg], acc[pg][ct]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < PER; ++j)
+                        if (j == rd && j * NM <= m * PER) { load_one(step + 2, (step + 2) % 3, j); ++rd; }
+                }
+                const int pg = m / CT, ct = m % CT;
+                acc[pg][ct] = mfma16x16x32(wf[cur][ct], pf[cur][pg], acc[pg][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -493,11 +512,23 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         }
     };
 
-    // tiles of this workgroup: blockIdx.x + k*gridDim.x; group `grp` takes k = grp, grp + 2, ...
-    const int stride = 2 * gridDim.x;
-    const int first = blockIdx.x + grp * gridDim.x;
-    const int my_count = first < total_tiles ? (total_tiles - first + stride - 1) / stride : 0;
-    const int cnt0 = (int)blockIdx.x < total_tiles ? (total_tiles - (int)blockIdx.x + stride - 1) / stride : 0;   // group 0's count >= group 1's
+    // tiles of this workgroup; group `grp` takes every second one.  XCD-contiguous bands (blockIdx & 7 = XCD, see
+    // bra_rows_persistent_kernel): neighbouring tiles' shared halo stays in one L2.
+    int first, first0, stride, limit;
+    if ((gridDim.x & 7) == 0 && !(stamps & 2)) {
+        const int per = gridDim.x >> 3, band = (total_tiles + 7) >> 3, start = (blockIdx.x & 7) * band;
+        limit = min(total_tiles, start + band);
+        first0 = start + (blockIdx.x >> 3);
+        first = first0 + grp * per;
+        stride = 2 * per;
+    } else {
+        limit = total_tiles;
+        first0 = blockIdx.x;
+        first = first0 + grp * gridDim.x;
+        stride = 2 * gridDim.x;
+    }
+    const int my_count = first < limit ? (limit - first + stride - 1) / stride : 0;
+    const int cnt0 = first0 < limit ? (limit - first0 + stride - 1) / stride : 0;   // group 0's count >= group 1's
     const int nphases = 2 * cnt0 + 1;               // uniform for the whole workgroup
 
     for (int nt = 0; nt < ntiles; ++nt) {
@@ -516,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
 
         // phase ph: group (ph & 1) runs the K loop of its tile k = ph >> 1; the other group stores its previous
         // tile and DMA-fetches its next one into its (now idle) buffer.  One workgroup barrier per phase.
-        const bool st_on = stamps && blockIdx.x == 100 && (threadIdx.x & 255) == 0 && nt == 0;
+        const bool st_on = (stamps & 1) && blockIdx.x == 100 && (threadIdx.x & 255) == 0 && nt == 0;
         auto stamp = [&](int ph, int i) { if (st_on && ph < 16) tup_conv_stamps[grp][ph][i] = __builtin_amdgcn_s_memtime(); };
         for (int ph = 0; ph < nphases; ++ph) {
             const int k = ph >> 1;
@@ -569,7 +600,7 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
-    static const int conv_stamps_on = getenv("TUP_CONV_STAMPS") ? 1 : 0;
+    static const int conv_stamps_on = (getenv("TUP_CONV_STAMPS") ? 1 : 0) | (getenv("TUP_CONV_NO_XCD_BANDS") ? 2 : 0);
     conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(512), lds, s>>>(
         (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, B, H, W, ntiles, r,
         cout_valid, relu, tilesX, tilesY, conv_stamps_on);

@@ -906,36 +906,40 @@ __global__ __launch_bounds__(512, 2) void patch_embed_kernel(const GemmParams p)
         const uint32_t sb = sbase + (uint32_t)((kc & 1) * STAGE);
         // quarter steps q = 0..3: K half kh = q >> 1, weight tiles (q & 1)*QN .. +QN
         bf16x8 tf[3][2], wf[3][QN];
-        auto ld = [&](int q, int slot) {
+        auto ld1 = [&](int q, int slot, int j) {               // j = 0, 1: token fragments; 2..: weight tiles of the quarter
             const int nb = (q & 1) * QN;
-            if (q >> 1) {
-                tf[slot][0] = lds_read_b128_asm_off_x64(sb + a_off0, 0);
-                tf[slot][1] = lds_read_b128_asm_off_x64(sb + a_off1, 0);
-#pragma unroll
-                for (int n = 0; n < QN; ++n) wf[slot][n] = lds_read_b128_asm_off_x64(sb + w_off, (nb + n) * 2048);
+            if (j < 2) {
+                const uint32_t a = sb + (j ? a_off1 : a_off0);
+                tf[slot][j] = (q >> 1) ? lds_read_b128_asm_off_x64(a, 0) : lds_read_b128_asm_off(a, 0);
             } else {
-                tf[slot][0] = lds_read_b128_asm_off(sb + a_off0, 0);
-                tf[slot][1] = lds_read_b128_asm_off(sb + a_off1, 0);
-#pragma unroll
-                for (int n = 0; n < QN; ++n) wf[slot][n] = lds_read_b128_asm_off(sb + w_off, (nb + n) * 2048);
+                wf[slot][j - 2] = (q >> 1) ? lds_read_b128_asm_off_x64(sb + w_off, (nb + j - 2) * 2048)
+                                           : lds_read_b128_asm_off(sb + w_off, (nb + j - 2) * 2048);
             }
         };
-        constexpr int PER = 2 + QN;
-        ld(0, 0);
-        ld(1, 1);
+        constexpr int PER = 2 + QN, NM = 2 * QN;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) ld1(0, 0, j);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) ld1(1, 1, j);
+        // the requests of quarter q + 2 are spread over quarter q's MFMAs (see conv_c64_persistent_kernel)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cur = q % 3;
-            if (q + 2 < 4) { ld(q + 2, (q + 2) % 3); lds_wait<(2 * PER > 15 ? 15 : 2 * PER)>(); }
-            else if (q + 1 < 4) { lds_wait<PER>(); }
-            else { lds_wait<0>(); }
+            if (q + 1 < 4) lds_wait<PER>(); else lds_wait<0>();
             __builtin_amdgcn_sched_barrier(0);
             const int nb = (q & 1) * QN;
+            int rd = 0;
 #pragma unroll
-            for (int tg = 0; tg < 2; ++tg)
+            for (int m = 0; m < NM; ++m) {
+                if (q + 2 < 4) {
 #pragma unroll
-                for (int n = 0; n < QN; ++n) acc[tg][nb + n] = mfma16x16x32(wf[cur][n], tf[cur][tg], acc[tg][nb + n]);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < PER; ++j)
+                        if (j == rd && j * NM <= m * PER) { ld1(q + 2, (q + 2) % 3, j); ++rd; }
+                }
+                const int tg = m / QN, n = m % QN;
+                acc[tg][nb + n] = mfma16x16x32(wf[cur][n], tf[cur][tg], acc[tg][nb + n]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 

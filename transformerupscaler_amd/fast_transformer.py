@@ -191,7 +191,10 @@ class TransformerModel(nn.Module):
                     pk["bra.w3"] = sd["up1_conv.conv.weight"].detach().float().contiguous()
                     pk["bra.comp"] = ops.bra_compose(pk["bra.wu"], pk["bra.bu"], pk["bra.w3"])
             hit = (ver, pk, frags_t, frags_n)
-            self._pack_cache = {key: hit}
+            # one entry per (scale, backward) of the CURRENT weights: alternating-scale inference / mixed-scale training re-packs
+            # nothing until a parameter changes (entries of an older version are dropped here)
+            self._pack_cache = {k: v for k, v in self._pack_cache.items() if v[0] == ver}
+            self._pack_cache[key] = hit
         return (hit[1], hit[2], hit[3]) if backward else (hit[1], hit[2])
 
     def forward(self, x: torch.Tensor, res_out: Tuple[int, int] = (1080, 1920), upscale_factor: Optional[int] = None,

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(
 __global__ __launch_bounds__(256, TUP_CONV1_OCC) void conv3x3_c3_persistent_kernel(
     const float* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ in_mask, const bf16_t* __restrict__ out_mask,
-    bf16_t* __restrict__ out, int H, int W, int relu, int tilesX, int tilesY, int ntiles)
+    bf16_t* __restrict__ out, int H, int W, int relu, int tilesX, int tilesY, int ntiles, int xcd_bands)
 {
     __shared__ __attribute__((aligned(16))) bf16_t lds[2][4 * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -197,8 +197,16 @@ __global__ __launch_bounds__(256, TUP_CONV1_OCC) void conv3x3_c3_persistent_kern
     };
 
     float vA[NST], vB[NST];
-    const int G = gridDim.x;
-    int t = blockIdx.x;
+    // tiles of this workgroup: XCD-contiguous bands (blockIdx & 7 = XCD): a 34-float halo row straddles two or three 128-B lines
+    // that the tiles left and right of it read too -- with neighbouring tiles on one XCD its L2 serves them (round-robin tiles
+    // fetched 269 MB for the 88 MB input)
+    int G = gridDim.x, t = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && xcd_bands) {
+        const int band = (ntiles + 7) >> 3, start = (blockIdx.x & 7) * band;
+        ntiles = min(ntiles, start + band);
+        t = start + (blockIdx.x >> 3);
+        G = gridDim.x >> 3;
+    }
     if (t < ntiles) load_tile(t, vA);
     if (t + G < ntiles) load_tile(t + G, vB);
     __syncthreads();                                        // zero fill done before the first staging stores
@@ -509,8 +517,9 @@ extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* b
         // per CU (a partial round) 330 us
         static const int per_cu = [] { const char* e = getenv("TUP_CONV1_WG_PER_CU"); return e ? atoi(e) : 2 * TUP_CONV1_OCC; }();
         const unsigned grid = (unsigned)(nblk < 256 * per_cu ? nblk : 256 * per_cu);
+        static const int xcd_bands = getenv("TUP_CONV1_NO_XCD_BANDS") ? 0 : 1;
         conv3x3_c3_persistent_kernel<<<dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-            x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY, (int)nblk);
+            x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY, (int)nblk, xcd_bands);
         TUP_CHECK_LAUNCH();
         return 0;
     }

@@ -169,6 +169,21 @@ TUP_DEVICE void gemm_store_row(const GemmParams& p, int m, int n0, int g, const 
 // The same epilogues split in two for the panel kernel: the operands an epilogue READS (residual row, skip pixels,
 // saved pre-activation) are requested before the K loop of the tile and consumed after it, so their HBM round trip
 // hides under the MFMAs instead of being paid between the K loop and the stores of every 64-column tile.
+// store sink for rows outside the output (keeps the number of store instructions per wave fixed); never read
+__device__ __attribute__((aligned(16))) unsigned int tup_gemm_sink[64 * 8];
+// 16-byte global loads the compiler does not track (no s_waitcnt of its own): the caller waits with a counted vmcnt and must
+// touch the outputs (asm "+v") only after that wait
+TUP_DEVICE u32x4 global_load_b128_async(const void* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+TUP_DEVICE u32x4 global_load_b128_async_16(const void* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
 struct EpiPre {
     u32x4 a[6];
     size_t off;          // E_UNEMBED: element offset of this lane's 16 channels
@@ -694,6 +709,102 @@ __global__ __launch_bounds__(256, 2) void gemm_panel2_kernel(const GemmParams p)
     }
 
     const uint32_t w_frag = lds_addr(smem) + (uint32_t)swz128(pl, g);
+    if constexpr (EPI == E_UNEMBED) {
+        // patch_unembed: 64 column tiles (one patch pixel each), every tile reads 16 KB of `skip` and writes 16 KB per workgroup.
+        // The `skip` lines of tile nt + 1 are requested at the top of tile nt: requested in their own tile they had one K loop
+        // (0.4 us) to arrive, and every tile waited out the HBM latency with only the CU's second workgroup to cover it.  The
+        // loads are asm (untracked), all waits counted: per tile and lane exactly 6 weight pieces, 4 skip loads, 4 stores (rows
+        // outside the map load the map's first pixel / store to the sink).  Two operand sets, the tile loop unrolled by two.
+        float bvec[16];
+        gemm_load_bias(p, 0, g, true, bvec);                   // [64] base channels: the same for every tile
+        size_t base[2];                                        // element offset of the patch origin (+ this lane's 16 channels)
+        int py0[2], px0[2];
+        bool tok_ok[2];
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            const int m = m0 + 32 * wave + 16 * tg + pl;
+            const TokPos t = token_of_row(min(m, p.M - 1), p);
+            tok_ok[tg] = t.valid && m < p.M;
+            py0[tg] = t.ty * 8; px0[tg] = t.tx * 8;
+            base[tg] = (((size_t)t.b * p.H) * p.W) * 64 + g * 16;
+        }
+        struct Ops { u32x4 a[2][2]; size_t off[2]; bool ok[2]; };
+        auto issue = [&](int nt, Ops& o) {
+            const int i = nt >> 3, j = nt & 7;
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                const int py = py0[tg] + i, px = px0[tg] + j;
+                o.ok[tg] = tok_ok[tg] && py < p.H && px < p.W;
+                o.off[tg] = base[tg] + ((size_t)py * p.W + px) * 64;
+                const bf16_t* sp = (p.skip ? p.skip : (const bf16_t*)p.out) + (o.ok[tg] ? o.off[tg] : (size_t)(g * 16));
+                o.a[tg][0] = global_load_b128_async(sp);
+                o.a[tg][1] = global_load_b128_async_16(sp);
+            }
+        };
+        auto tile = [&](int nt, Ops& cur, Ops& nx) {
+            // own pieces of W tile nt (requested a tile ago); younger: the 4 skip loads of tile nt, the 4 stores of tile nt-1
+            if (nt > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everyone's pieces landed; everyone finished reading tile nt-1
+            if (nt + 1 < ntiles) { dma_w(nt + 1, (nt + 1) & 1); issue(nt + 1, nx); }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint32_t wb = w_frag + (uint32_t)((nt & 1) * PW_BYTES);
+            bf16x8 wf[3][4];
+            auto ld = [&](int step, int slot) {
+                const int kc = step >> 1;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    wf[slot][ct] = (step & 1) ? lds_read_b128_asm_off_x64(wb, kc * (64 * 128) + ct * 2048)
+                                              : lds_read_b128_asm_off(wb, kc * (64 * 128) + ct * 2048);
+            };
+            ld(0, 0);
+            ld(1, 1);
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const int c3 = step % 3;
+                if (step + 2 < 6) { ld(step + 2, (step + 2) % 3); lds_wait<8>(); }
+                else if (step + 1 < 6) { lds_wait<4>(); }
+                else { lds_wait<0>(); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tg = 0; tg < 2; ++tg)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) acc[tg][ct] = mfma16x16x32(wf[c3][ct], tf[tg][step], acc[tg][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // this tile's skip lines, requested a tile ago; younger: the stores of tile nt-1 (4), W pieces (6) + skip loads (4) of nt+1
+            if (nt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+            for (int tg = 0; tg < 2; ++tg) {
+                asm volatile("" : "+v"(cur.a[tg][0]), "+v"(cur.a[tg][1]));      // the loads' outputs are live only from here
+                uint32_t pk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    uint32_t sw = (q < 4) ? cur.a[tg][0][q & 3] : cur.a[tg][1][q & 3];
+                    if (!p.skip) sw = 0u;
+                    const int ct = q >> 1, e = (q & 1) * 2;
+                    pk[q] = pack_bf16x2(acc[tg][ct][e] + bvec[2 * q] + __builtin_bit_cast(float, sw << 16),
+                                        acc[tg][ct][e + 1] + bvec[2 * q + 1] + __builtin_bit_cast(float, sw & 0xffff0000u));
+                }
+                bf16_t* o = cur.ok[tg] ? (bf16_t*)p.out + cur.off[tg] : reinterpret_cast<bf16_t*>(tup_gemm_sink) + lane * 16;
+                *reinterpret_cast<u32x4*>(o) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+                *reinterpret_cast<u32x4*>(o + 8) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+            }
+        };
+        Ops A, B;
+        issue(0, A);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // own pieces of W tile 0 (and tile 0's skip lines)
+        for (int nt = 0; nt < ntiles; nt += 2) {
+            tile(nt, A, B);
+            if (nt + 1 < ntiles) tile(nt + 1, B, A);
+        }
+        return;
+    }
     float cs[EPI == E_UNEMBED_MERGE ? 16 : 1] = {};            // E_UNEMBED_MERGE: column sums of `skip` (this lane's 16 channels)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // own pieces of W tile 0
     for (int nt = 0; nt < ntiles; ++nt) {

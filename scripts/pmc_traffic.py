@@ -21,14 +21,14 @@ KEYS = {
         "tail": ("tail_stream_r2_kernel<true>", "tail_stream.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
         "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", 1920 * 64 * 192 * 4 + 2 * 8 * F64),
         "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip", 8 * F64 + 1920 * 64 * 192 * 4),
-        "branch_a_5x5": ("conv_c64_persistent_kernel<1, 1, 5>", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 1440 * 2560 * 4),
+        "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 1440 * 2560 * 4),
         "conv1": ("conv3x3_c3_persistent_kernel", "conv_thin.hip", 8 * 3 * 720 * 1280 * 4 + 8 * F64),
-        "decoder_conv2": ("conv_c64_persistent_kernel<1, 1, 3>", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 720 * 1280 * 4),
+        "decoder_conv2": ("conv3_thin_rows_kernel", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 720 * 1280 * 4),
     },
     "x4": {      # B = 4, 4x 540p -> 2160p: the tail's last stage runs 1080p -> 2160p without a Resize
         "tail": ("tail_stream_r2_kernel<false>", "tail_stream.hip", 4 * 3 * (1080 * 1920 + 2 * 2160 * 3840) * 4),
         "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 540 * 64 * 192 * 4 * 2),        # 4 x 135 windows
-        "branch_a_5x5": ("conv_c64_persistent_kernel<1, 1, 5>", "conv3x3_c64.hip", 4 * 1080 * 1920 * 64 * 2 + 4 * 3 * 2160 * 3840 * 4),
+        "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip", 4 * 1080 * 1920 * 64 * 2 + 4 * 3 * 2160 * 3840 * 4),
     },
     "train": {   # B = 4, 2x 720p -> 1080p training step
         "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 2 * 192 * 2 + 576 * 2) + 960 * 12 * 64 * 4),      # qkv, d att, att, lse in; d qkv out

@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
             const int k = ph >> 1;
             stamp(ph, 0);
             if ((ph & 1) == grp) {
-                if (k < my_count) compute_tile();
+                if (k < my_count && !(stamps & 16)) compute_tile();
                 stamp(ph, 1);
             } else {
                 // group 0 is here on odd phases (just computed tile k, next is k+1); group 1 on even phases
@@ -562,9 +562,9 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 const int nxt = done + 1;
                 // DMA first: it then has the whole phase (the other group's K loop) to land; the buffer is idle
                 // because this group's own K loop ended before the last barrier
-                if (nxt < my_count) prefetch_tile(first + nxt * stride);
+                if (nxt < my_count && !(stamps & 8)) prefetch_tile(first + nxt * stride);
                 stamp(ph, 1);
-                if (done >= 0 && done < my_count) {
+                if (done >= 0 && done < my_count && !(stamps & 4)) {
                     store_tile(first + done * stride, nt);
                     stamp(ph, 2);
                     // The DMA (issued first) must have landed before the barrier; the 8 stores issued after it need
@@ -600,7 +600,10 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
-    static const int conv_stamps_on = (getenv("TUP_CONV_STAMPS") ? 1 : 0) | (getenv("TUP_CONV_NO_XCD_BANDS") ? 2 : 0);
+    // bit 0: s_memtime stamps; bit 1: round-robin tiles instead of XCD bands; timing experiments (wrong results): TUP_CONV_ABLATE
+    // bits 4 = no stores, 8 = no DMA, 16 = no K loop
+    static const int conv_stamps_on = (getenv("TUP_CONV_STAMPS") ? 1 : 0) | (getenv("TUP_CONV_NO_XCD_BANDS") ? 2 : 0) |
+                                      (getenv("TUP_CONV_ABLATE") ? (atoi(getenv("TUP_CONV_ABLATE")) & 28) : 0);
     conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(512), lds, s>>>(
         (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, B, H, W, ntiles, r,
         cout_valid, relu, tilesX, tilesY, conv_stamps_on);

@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 P = c_void_p
 I = c_int
@@ -22,6 +22,7 @@ U = c_uint
 SIGNATURES = {
     "tup_abi_version": [],
     "tup_conv3x3_c3_fwd": [P, P, P, P, P, P, I, I, I, I, P],
+    "tup_conv1_conv2_fwd": [P, P, P, P, P, P, I, I, I, P],
     "tup_conv3x3_c64_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "tup_conv5x5_c64_planar_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "tup_conv3x3_planar_fwd": [P, P, P, P, P, I, I, I, I, I, P],

@@ -48,6 +48,9 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
 
 
 blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
+# inference: conv1 + conv2 in one kernel (tup_conv1_conv2_fwd).  OFF by default: bit-identical to the two kernels, but at 8 x 720p
+# 0.98 ms against their 0.74 ms (conv1's per-tile phase is longer than the K loop it should hide under)
+fuse_conv12 = bool(os.environ.get("TUP_FUSE_CONV12"))
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
@@ -108,10 +111,14 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
     cap = capture
     x = x.contiguous().float()
     B, _, H, W = x.shape
-    feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
-    with _stage("conv2"):
-        feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
-    del feat1
+    if fuse_conv12 and cap is None:
+        with _stage("conv2"):                      # conv1 + ReLU + conv2 + ReLU in one kernel: conv1's output never exists in HBM
+            feat = ops.conv1_conv2(x, pk["conv1.w"], pk["conv1.b"], pk["conv2.w"], pk["conv2.b"])
+    else:
+        feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
+        with _stage("conv2"):
+            feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+        del feat1
     # branch A: Upsampler + up1_conv (conv, no bias, ReLU)
     stages = upsampler_layout(scale)
     up = feat

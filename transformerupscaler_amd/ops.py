@@ -91,6 +91,16 @@ def conv1(x, wp, bias, relu=True, in_mask=None, out_mask=None):
     return out
 
 
+def conv1_conv2(x, w1, b1, wp, bias):
+    """conv1 + ReLU + conv2 + ReLU in one kernel (inference): planar fp32 [B][3][H][W] -> NHWC bf16 [B][H][W][64]."""
+    B, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty((B, H, W, 64), dtype=BF16, device=x.device)
+    _lib.call("tup_conv1_conv2_fwd", _chk(x, F32, None, "x"), _chk(w1, BF16, (64, 32), "w1"), _chk(b1, F32, (64,), "b1"),
+              _chk(wp, BF16, (1, 1, 9, 64, 64), "wp"), _chk(bias, F32, (1, 64), "bias"), out.data_ptr(), B, H, W, _stream())
+    return out
+
+
 def conv_c64(x, wp, bias, r=1, relu=False, add=None, mask=None, in_r=1):
     """NHWC bf16 conv 64*in_r^2 -> 64*r*r with fused PixelShuffle(r); returns [B][H*r][W*r][64] bf16.
     x is [B][H*in_r][W*in_r][64] (in_r > 1: channels read through PixelShuffle^-1)."""

@@ -577,11 +577,13 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         asm volatile("" : "+v"(ln));
         const int g = ln >> 4, p = ln & 15;           // (shadow the kernel's: see conv1_load)
         bf16_t* stg = reinterpret_cast<bf16_t*>(in_lds + 2 * IN_BYTES + 256) + wave * STG;
+        // gather offsets of this lane's eight K values (k >= 27: any finite element -- zeroed after the read); pixel px = 16 gq + p
+        // is "+ p" in the base and an immediate 32 gq bytes: all 24 reads of a row are requested before the first is used
         int koff1[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = 8 * g + j, tap = k / 3, c = k - tap * 3, dy = tap / 3, dx = tap - dy * 3;
-            koff1[j] = k < 27 ? c * 108 + dy * 36 + dx : 324;
+            const int k = min(8 * g + j, 26), tap = k / 3, c = k - tap * 3, dy = tap / 3, dx = tap - dy * 3;
+            koff1[j] = c * 108 + dy * 36 + dx + p;
         }
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
@@ -592,22 +594,33 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 const int idx = ln + 64 * u;
                 if (idx < 324) stg[idx] = f32_to_bf16(v[rr][u]);
             }
+            bf16x8 pf[3];
+#pragma unroll
+            for (int gq = 0; gq < 3; ++gq)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[gq][j] = stg[koff1[j] + 16 * gq];       // (columns >= 36 of group 2: discarded below)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int gq = 0; gq < 3; ++gq) {
-                const int px = 16 * gq + p, pxc = min(px, HALO_W - 1);
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = stg[koff1[j] + pxc];
+                const int px = 16 * gq + p;
+                u32x4 pw = __builtin_bit_cast(u32x4, pf[gq]);
+                if (g == 3) { pw[1] &= 0xffffu; pw[2] = 0u; pw[3] = 0u; }             // k = 27 .. 31
                 f32x4 a1[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) a1[ct] = mfma16x16x32(w1f[ct], pf, b1v[ct]);
+                for (int ct = 0; ct < 4; ++ct) a1[ct] = mfma16x16x32(w1f[ct], __builtin_bit_cast(bf16x8, pw), b1v[ct]);
                 const int ix = tx * TW - 1 + px;
                 const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
                 uint32_t pk[8];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    pk[ct * 2 + 0] = inside ? pack_bf16x2(fmaxf(a1[ct][0], 0.f), fmaxf(a1[ct][1], 0.f)) : 0u;
-                    pk[ct * 2 + 1] = inside ? pack_bf16x2(fmaxf(a1[ct][2], 0.f), fmaxf(a1[ct][3], 0.f)) : 0u;
+                    pk[ct * 2 + 0] = pack_bf16x2(a1[ct][0], a1[ct][1]);
+                    pk[ct * 2 + 1] = pack_bf16x2(a1[ct][2], a1[ct][3]);
+                }
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {        // ReLU on the packed pairs (negative bf16 = negative int16), zero outside the image
+                    pk[w] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[w]), s16x2{0, 0}));
+                    pk[w] = inside ? pk[w] : 0u;
                 }
                 if (px < HALO_W) {                   // lane (g, p): channels 16 g .. 16 g + 15 of halo pixel q = two 16-byte chunks
                     const int q = yy * HALO_W + px;
@@ -1128,7 +1141,7 @@ int launch_conv1_conv2(const float* x3, const void* w1, const float* b1, const v
                        int B, int H, int W, hipStream_t s)
 {
     constexpr int NPIX_HALO = (TH + 2) * (TW + 2);
-    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * (size_t)NPIX_HALO * 128 + 256 + 4 * 326 * 2;    // + bias + staging lines
+    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * (size_t)NPIX_HALO * 128 + 256 + 4 * 326 * 2 + 64;    // + bias + staging lines + pad
     static_assert(lds <= 163840, "LDS budget");
     TUP_SET_DYN_LDS((conv_c64_persistent_kernel<4, OUT_NHWC_BF16, 3, true>), lds);
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;

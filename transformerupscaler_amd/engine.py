@@ -49,7 +49,7 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
 
 blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
 # inference: conv1 + conv2 in one kernel (tup_conv1_conv2_fwd).  OFF by default: bit-identical to the two kernels, but at 8 x 720p
-# 0.98 ms against their 0.74 ms (conv1's per-tile phase is longer than the K loop it should hide under)
+# 0.92 ms against their 0.73 ms (the VALU work of conv1 in the idle wave group comes out of the K loop's MFMA issue)
 fuse_conv12 = bool(os.environ.get("TUP_FUSE_CONV12"))
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)

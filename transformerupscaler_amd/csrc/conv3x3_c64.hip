@@ -280,7 +280,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     char* w_lds = smem;                              // [NTAPS][WROWS][128 B]
     char* in_lds = smem + NTAPS * WSLAB;             // [2 groups][IN_BYTES]
 
-    const int grp = threadIdx.x >> 8;                // wave group 0 / 1
+    // wave group 0 / 1; scalar so that the tile bookkeeping runs on the SALU (the FUSE1 build is out of SGPRs and keeps it per lane)
+    const int grp = FUSE1 ? (int)(threadIdx.x >> 8) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // indices inside the group
     const int g = lane >> 4, p = lane & 15;
     const int total_tiles = tilesX * tilesY * B;
@@ -301,11 +302,12 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     }
     constexpr bool LAST_PARTIAL = (IN_CHUNKS % 256) != 0;
     const bool last_ok = (NPIECE - 1) * 256 + tid < IN_CHUNKS;
-    auto prefetch_tile = [&](int tile) {
-        int t = tile;
-        const int tx = t % tilesX; t /= tilesX;
-        const int ty = t % tilesY;
-        const int b = t / tilesY;
+    // Tile coordinates are carried, not decoded: a tile index -> (tx, ty, b) decode is two integer divisions = ~30 VALU
+    // instructions each even for a wave-uniform value, twice per phase, and every VALU instruction of the idle wave group costs the
+    // other group's K loop ~5 cycles of MFMA issue.  A group's tiles advance by a fixed stride: one carry chain per phase.
+    struct TC { int tx, ty, b; };
+    auto prefetch_tile = [&](const TC& c) {
+        const int tx = c.tx, ty = c.ty, b = c.b;
         const int ty0 = ty * TH, tx0 = tx * TW;
         const char* xb = reinterpret_cast<const char*>(x + (size_t)b * H * W * 64);
         if (ty0 >= PADK && ty0 + TH + PADK <= H && tx0 >= PADK && tx0 + TW + PADK <= W) {       // interior tile
@@ -423,11 +425,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         }
     };
 
-    auto store_tile = [&](int tile, int nt) {
-        int t = tile;
-        const int tx = t % tilesX; t /= tilesX;
-        const int ty = t % tilesY;
-        const int b = t / tilesY;
+    auto store_tile = [&](const TC& c, int nt) {
+        const int tx = c.tx, ty = c.ty, b = c.b;
 #pragma unroll
         for (int pg = 0; pg < 4; ++pg) {
             const int oy = ty * TH + 2 * wave + (pg >> 1);
@@ -649,6 +648,15 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     const int my_count = first < limit ? (limit - first + stride - 1) / stride : 0;
     const int cnt0 = first0 < limit ? (limit - first0 + stride - 1) / stride : 0;   // group 0's count >= group 1's
     const int nphases = 2 * cnt0 + 1;               // uniform for the whole workgroup
+    auto decode = [&](int tile) { TC c; c.tx = tile % tilesX; const int t = tile / tilesX; c.ty = t % tilesY; c.b = t / tilesY; return c; };
+    const TC c_first = decode(first);
+    const int step_x = stride % tilesX, step_y = (stride / tilesX) % tilesY, step_b = stride / (tilesX * tilesY);
+    auto advance = [&](TC& c) {                       // + stride tiles
+        c.tx += step_x;
+        if (c.tx >= tilesX) { c.tx -= tilesX; ++c.ty; }
+        c.ty += step_y; c.b += step_b;
+        if (c.ty >= tilesY) { c.ty -= tilesY; ++c.b; }
+    };
 
     for (int nt = 0; nt < ntiles; ++nt) {
         stage_weights(nt);
@@ -669,9 +677,12 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 conv1_compute(first, v, w1f, b1v);
             }
         } else {
-            if (grp == 0 && my_count > 0) prefetch_tile(first);
+            if (grp == 0 && my_count > 0) prefetch_tile(c_first);
         }
         __syncthreads();            // weights + group 0's first tile visible (the barrier's vmcnt(0) retires the DMA)
+        // c_done = the tile this group computed last (to be stored), c_next = the one to fetch next
+        TC c_done = c_first, c_next = c_first;
+        if (grp == 0) advance(c_next);
 
         // phase ph: group (ph & 1) runs the K loop of its tile k = ph >> 1; the other group stores its previous
         // tile and DMA-fetches its next one into its (now idle) buffer.  One workgroup barrier per phase.
@@ -694,7 +705,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                     float v[3][6]; bf16x8 w1f[4]; f32x4 b1v[4];
                     const bool have_next = nxt < my_count;
                     if (have_next) conv1_load(first + nxt * stride, v, w1f, b1v);
-                    if (done >= 0 && done < my_count) store_tile(first + done * stride, nt);
+                    if (done >= 0 && done < my_count) store_tile(decode(first + done * stride), nt);
                     if (have_next) conv1_compute(first + nxt * stride, v, w1f, b1v);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
@@ -702,10 +713,10 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 }
                 // DMA first: it then has the whole phase (the other group's K loop) to land; the buffer is idle
                 // because this group's own K loop ended before the last barrier
-                if (nxt < my_count && !(stamps & 8)) prefetch_tile(first + nxt * stride);
+                if (nxt < my_count && !(stamps & 8)) prefetch_tile(c_next);
                 stamp(ph, 1);
                 if (done >= 0 && done < my_count && !(stamps & 4)) {
-                    store_tile(first + done * stride, nt);
+                    store_tile(c_done, nt);
                     stamp(ph, 2);
                     // The DMA (issued first) must have landed before the barrier; the 8 stores issued after it need
                     // not: vmcnt counts in issue order, so "all but the youngest 8" = the DMA.  (A __syncthreads()
@@ -716,6 +727,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                c_done = c_next;                     // the tile just fetched is computed next and stored in this group's next idle phase
+                advance(c_next);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stamp(ph, 3);

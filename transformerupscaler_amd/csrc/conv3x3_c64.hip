@@ -786,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void bra_rows_persistent_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w_lds = smem;                              // [5 dy][64 rows][128 B]
     char* in_lds = smem + R5_W_BYTES;                // [2 groups][R5_IN_BYTES]
-    const int grp = threadIdx.x >> 8;
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));      // scalar: tile bookkeeping on the SALU
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, p = lane & 15;
     const int total_tiles = tilesX * tilesY * B;
@@ -802,11 +802,9 @@ __global__ __launch_bounds__(512, 2) void bra_rows_persistent_kernel(
         const int yy = q / R5_HW, xx = q - yy * R5_HW;
         rel[it] = ((yy - 2) * W + (xx - 2)) * 128 + c * 16;
     }
-    auto prefetch_tile = [&](int tile) {
-        int t = tile;
-        const int tx = t % tilesX; t /= tilesX;
-        const int ty = t % tilesY;
-        const int b = t / tilesY;
+    struct TC { int tx, ty, b; };                    // tile coordinates are carried across phases, not decoded (conv_c64_persistent_kernel)
+    auto prefetch_tile = [&](const TC& c) {
+        const int tx = c.tx, ty = c.ty, b = c.b;
         const int ty0 = ty * TH, tx0 = tx * R5_TW;
         const char* xb = reinterpret_cast<const char*>(x + (size_t)b * H * W * 64);
         if (ty0 >= 2 && ty0 + TH + 2 <= H && tx0 >= 2 && tx0 + R5_HW - 2 <= W) {          // interior tile
@@ -900,11 +898,8 @@ __global__ __launch_bounds__(512, 2) void bra_rows_persistent_kernel(
     // v_add_f32 with a DPP source (hipcc keeps a v_mov_b32_dpp + v_add_f32 pair per term: 154 instead of 82 instructions, and
     // every VALU instruction of this phase takes issue cycles from the other group's MFMA stream on the same SIMD)
 #define TUP_ADD_DPP(acc, v, ctrl) asm("v_add_f32_dpp %0, %1, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(v))
-    auto store_tile = [&](int tile) {
-        int t = tile;
-        const int tx = t % tilesX; t /= tilesX;
-        const int ty = t % tilesY;
-        const int b = t / tilesY;
+    auto store_tile = [&](const TC& c) {
+        const int tx = c.tx, ty = c.ty, b = c.b;
         const int Wr = W * 2, si = g >> 1, sj = g & 1;
         const int plane = 4 * H * W;                 // elements of one HR plane
         float* outb = out + (size_t)b * 3 * plane;
@@ -958,7 +953,21 @@ __global__ __launch_bounds__(512, 2) void bra_rows_persistent_kernel(
     const int cnt0 = first0 < limit ? (limit - first0 + stride - 1) / stride : 0;      // group 0's count >= group 1's
     const int nphases = 2 * cnt0 + 1;               // uniform for the whole workgroup
 
-    if (grp == 0 && my_count > 0) prefetch_tile(first);
+    TC c_done, c_next;
+    {
+        const int t = first / tilesX;
+        c_done.tx = first - t * tilesX; c_done.ty = t % tilesY; c_done.b = t / tilesY;
+        c_next = c_done;
+    }
+    const int step_x = stride % tilesX, step_y = (stride / tilesX) % tilesY, step_b = stride / (tilesX * tilesY);
+    auto advance = [&](TC& c) {                       // + stride tiles
+        c.tx += step_x;
+        if (c.tx >= tilesX) { c.tx -= tilesX; ++c.ty; }
+        c.ty += step_y; c.b += step_b;
+        if (c.ty >= tilesY) { c.ty -= tilesY; ++c.b; }
+    };
+    if (grp == 0 && my_count > 0) prefetch_tile(c_next);
+    if (grp == 0) advance(c_next);
     __syncthreads();
     for (int ph = 0; ph < nphases; ++ph) {
         const int k = ph >> 1;
@@ -967,14 +976,16 @@ __global__ __launch_bounds__(512, 2) void bra_rows_persistent_kernel(
         } else {
             const int done = grp == 0 ? k : k - 1;
             const int nxt = done + 1;
-            if (nxt < my_count && !(ablate & 4)) prefetch_tile(first + nxt * stride);
+            if (nxt < my_count && !(ablate & 4)) prefetch_tile(c_next);
             if (done >= 0 && done < my_count && !(ablate & 2)) {
-                store_tile(first + done * stride);
+                store_tile(c_done);
                 // the DMA (issued first) must have landed before the barrier, the 12 stores after it need not
                 asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            c_done = c_next;                         // the tile just fetched: computed next, stored in this group's next idle phase
+            advance(c_next);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

@@ -19,7 +19,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
     "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip"),
-    "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip"),
+    "conv64": ("conv_c64_persistent_kernel<4, 0, 3, false>", "conv3x3_c64.hip"),
     "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip"),
     "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip"),
     "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip"),

@@ -17,7 +17,7 @@ F64 = 720 * 1280 * 64 * 2            # one 64-channel bf16 map of a 720p image
 KEYS = {
     "infer": {   # B = 8, 2x 720p -> 1080p
         "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 1920 * 64 * 192 * 4 * 2),      # six blocks per launch
-        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 8 * F64),
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3, false>", "conv3x3_c64.hip", 2 * 8 * F64),
         "tail": ("tail_stream_r2_kernel<true>", "tail_stream.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
         "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", 1920 * 64 * 192 * 4 + 2 * 8 * F64),
         "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip", 8 * F64 + 1920 * 64 * 192 * 4),
@@ -32,7 +32,7 @@ KEYS = {
     },
     "train": {   # B = 4, 2x 720p -> 1080p training step
         "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 2 * 192 * 2 + 576 * 2) + 960 * 12 * 64 * 4),      # qkv, d att, att, lse in; d qkv out
-        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 4 * F64),
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3, false>", "conv3x3_c64.hip", 2 * 4 * F64),
         "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip", 2 * 4 * F64),
         "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),          # only when H or W is not a multiple of 8
         "pe_bwd_merge": ("gemm_panel2_kernel<1, 6>", "gemm_tokens.hip", 960 * 64 * 192 * 4 + 4 * 4 * F64),      # tokens in; two adds, the gate map in, the merged gradient out

@@ -134,6 +134,17 @@ __global__ __launch_bounds__(256, 2) void fused_qkv_attn_kernel(
     const float* x = PROJ ? xio : x_in;
     static_assert(!MLP || PROJ, "the MLP half follows the proj");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    {   // One of a CU's two resident workgroups runs at wave priority 3 (the high half of nblk carries "shift + 1 | level << 5";
+        // the dispatcher fills the CUs once before it doubles up, so workgroups j and j + #CUs share a CU: bit log2(#CUs) of
+        // blockIdx).  With equal priorities the two waves of a SIMD contend for every issue slot and drift in and out of phase;
+        // a fixed pecking order lets one stream its MFMA segments while the other fills the gaps: 973-987 -> 961-962 us for the
+        // six-block launch at 1,920 windows (levels 1 / 2: 965-970 / 938-965; the other bit positions: no effect).
+        const int pr = nblk >> 16, pshift = pr & 31, lvl = pr >> 5;
+        nblk &= 0xffff;
+        if (pshift && ((blockIdx.x >> (pshift - 1)) & 1)) {
+            if (lvl == 3) __builtin_amdgcn_s_setprio(3); else if (lvl == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+        }
+    }
     unsigned long long ph[NPH32] = {}, tprev = 0, tstart = 0;
     if constexpr (STAMPS) tprev = tstart = stamp_now32();
 #define B32_STAMP(K) do { if constexpr (STAMPS) { const unsigned long long t_ = stamp_now32(); ph[K] += t_ - tprev; tprev = t_; } } while (0)
@@ -751,7 +762,18 @@ int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* str
         fused_qkv_attn_kernel<true, true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
     } else {
         TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
-        fused_qkv_attn_kernel<true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
+        // wave priority of every second resident set (see the kernel's first lines); TUP_BLOCK_PRIO=0 switches it off
+        static const int prio = [] {
+            const char* e = getenv("TUP_BLOCK_PRIO");
+            if (e) return atoi(e);
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+            if (cus <= 0 || (cus & (cus - 1))) return 0;         // the bit test needs a power of two (MI355X: 256)
+            int sh = 0;
+            while ((1 << sh) < cus) ++sh;
+            return (sh + 1) | (3 << 5);
+        }();
+        fused_qkv_attn_kernel<true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk | (prio << 16));
     }
     TUP_CHECK_LAUNCH();
     return 0;

@@ -26,13 +26,6 @@ extern "C" {
 /* library / ABI version, bumped when a signature changes */
 int tup_abi_version(void);
 
-/* conv1 + ReLU + conv2 + ReLU in one kernel (inference; replaces F.relu(self.conv1(x)) ; F.relu(self.conv2(.)),
- * reference models/FastTransformer/model.py:251-252): the 64-channel map between the two convs is computed per tile in LDS and
- * never written.  x3 fp32 [B][3][H][W]; w1 bf16 [64][32] and b1 fp32 [64] as tup_conv3x3_c3_fwd takes them; wp bf16
- * [1][1][9][64][64] and bias fp32 [64] as tup_conv3x3_c64_fwd takes them; out bf16 NHWC [B][H][W][64]. */
-int tup_conv1_conv2_fwd(const float* x3, const void* w1, const float* b1, const void* wp, const float* bias, void* out,
-                        int B, int H, int W, void* stream);
-
 /* conv1: Conv2d(3,64,k3,p1)+ReLU. model.py:202-203,251.
  * x fp32 [B][3][H][W]; wp bf16 [64][32] (row ct*16+4g+e = channel g*16+ct*4+e, k = tap*3+cin,
  * zero pad 27..31); bias fp32 [64] or NULL; out bf16 NHWC.

@@ -288,3 +288,32 @@ def test_integration_md_ctypes_snippet_matches_header():
                 cur += ch
         nargs += bool(cur.strip())
         assert nargs == len(_lib.SIGNATURES[name]), (name, nargs, len(_lib.SIGNATURES[name]))
+
+
+def test_tail_routing_respects_the_streaming_tails_offset_limits(monkeypatch):
+    """engine.forward must not hand the streaming tail (32-bit byte offsets, csrc/tail_stream.hip) a batch it refuses: beyond
+    B*12*H*W = 2^29 elements of the last stage's HR map (or B*3*Ho*Wo of the resized output) the tiled tail takes over."""
+    from transformerupscaler_amd import engine, ops
+    assert ops.tail_stream_fits(8, 720, 1280) and ops.tail_stream_fits(8, 720, 1280, (1080, 1920))
+    assert ops.tail_stream_fits(12, 1440, 2560) and not ops.tail_stream_fits(13, 1440, 2560)        # 4x of 720p: fails from B = 13
+    assert ops.tail_stream_fits(21, 1080, 1920) and not ops.tail_stream_fits(22, 1080, 1920)        # 540p -> 2160p: from B = 22
+    assert ops.tail_stream_fits(1, 64, 64, (128, 128))                                               # identity "resize" = no resize
+    assert not ops.tail_stream_fits(1, 4000, 4000, (7999, 7999 * 3))                                 # the resized output's own limit
+    # the router itself, with the kernels replaced by recorders (no GPU): an oversized last stage must reach tail_fused
+    calls = []
+    big = torch.empty((13, 3, 1440, 2560), device="meta")
+    monkeypatch.setattr(ops, "tail_stream_r2", lambda *a, **k: calls.append("stream") or "s")
+    monkeypatch.setattr(ops, "tail_fused", lambda *a, **k: calls.append("tiled") or "t")
+    src = inspect.getsource(engine.forward)
+    assert "ops.tail_stream_fits(" in src and src.index("ops.tail_stream_fits(") < src.index("ops.tail_stream_r2(")
+    fits = ops.tail_stream_fits(big.shape[0], big.shape[2], big.shape[3], None)
+    (ops.tail_stream_r2 if fits else ops.tail_fused)(big)
+    assert calls == ["tiled"]
+
+
+def test_rt_attention_dropout_on_an_unsupported_token_count_raises_a_clear_error():
+    from transformerupscaler_amd import ops
+    with pytest.raises(ValueError, match="multiple of 4"):
+        ops.rt_attention(torch.empty((2 * 506, 384), dtype=torch.bfloat16), 2, 506, drop_p=0.1)
+    with pytest.raises(ValueError, match="multiple of 4"):
+        ops.rt_attention_bwd(None, None, None, None, 1, 22 * 23, drop_p=0.1)

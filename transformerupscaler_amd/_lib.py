@@ -22,7 +22,6 @@ U = c_uint
 SIGNATURES = {
     "tup_abi_version": [],
     "tup_conv3x3_c3_fwd": [P, P, P, P, P, P, I, I, I, I, P],
-    "tup_conv1_conv2_fwd": [P, P, P, P, P, P, I, I, I, P],
     "tup_conv3x3_c64_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P],
     "tup_conv5x5_c64_planar_fwd": [P, P, P, P, P, P, I, I, I, I, I, P],
     "tup_conv3x3_planar_fwd": [P, P, P, P, P, I, I, I, I, I, P],

@@ -35,9 +35,7 @@ EXEMPT = re.compile(r"fused_qkv_attn_kernel<true, true, true>|fused_qkv_attn_ker
 #    before the chunk loop.
 # Extra vmcnt-counted operations YOUNGER than a DMA piece make a counted wait stricter (slower), never weaker; the failure mode the
 # guard exists for is a build whose spill reloads land inside the head / chunk loops, which these two caps would catch as growth.
-#  * conv_c64_persistent_kernel<4,0,3,FUSE1=true> (conv1 inside conv2): that instantiation has NO counted vmcnt wait (no LDS-DMA: its
-#    input image is computed, and its stores are followed by a barrier only), so scratch there costs time, not correctness.
-ALLOWED_BYTES = {"fused_mlp_v2_kernelILi0E": 72, "conv_c64_persistent_kernelILi4ELi0ELi3ELb1E": 96}
+ALLOWED_BYTES = {"fused_mlp_v2_kernelILi0E": 72}
 
 FIELDS = {
     "sgprs": r"TotalSGPRs: (\d+)", "vgprs": r" VGPRs: (\d+)", "agprs": r"AGPRs: (\d+)",

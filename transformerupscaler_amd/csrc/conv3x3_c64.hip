@@ -257,20 +257,12 @@ __device__ __attribute__((aligned(16))) unsigned int tup_store_sink[64 * 8];
 // 2 = stores issued, 3 = vmcnt wait over, 4 = barrier passed]
 __device__ unsigned long long tup_conv_stamps[2][16][5];
 
-// FUSE1 (inference, conv1 + ReLU + conv2 + ReLU in one kernel, tup_conv1_conv2_fwd): the 64-channel input image of a tile is
-// not DMA-fetched but COMPUTED by the idle wave group from the 3-channel fp32 input x3 -- conv1 (K = 27 -> 32, one MFMA K-step,
-// weights w1 bf16 [64][32] as conv3x3_c3_persistent_kernel takes them) + bias + ReLU for the tile's 10 x 34 halo pixels, written
-// as bf16 into the same swizzled LDS image the K loop reads; conv1 outputs outside the image are zero (conv2's padding).  conv1's
-// 118 MB-per-image output is neither written nor read: by the ablations in DESIGN 5c conv2 spends 372 of its 436 us on memory.
-// Per wave of the group: halo rows w, w + 4, w + 8; per row the 3 x 3 x 36 input window goes through a 652-byte wave-private
-// staging line (bf16) and is gathered into im2col fragments from there; 88 MFMAs per tile on top of the K loop's 1,152.
-template <int CT, int OUT_MODE, int KS, bool FUSE1 = false>
+template <int CT, int OUT_MODE, int KS>
 __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
     const bf16_t* __restrict__ add, const bf16_t* __restrict__ mask,
     void* __restrict__ out, int B, int H, int W, int ntiles, int r, int cout_valid, int relu,
-    int tilesX, int tilesY, int stamps, const float* __restrict__ x3 = nullptr, const bf16_t* __restrict__ w1 = nullptr,
-    const float* __restrict__ b1 = nullptr)
+    int tilesX, int tilesY, int stamps)
 {
     constexpr int PADK = KS / 2, HALO_W = TW + KS - 1, HALO_H = TH + KS - 1, NPIX_HALO = HALO_H * HALO_W;
     constexpr int NTAPS = KS * KS;
@@ -280,8 +272,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
     char* w_lds = smem;                              // [NTAPS][WROWS][128 B]
     char* in_lds = smem + NTAPS * WSLAB;             // [2 groups][IN_BYTES]
 
-    // wave group 0 / 1; scalar so that the tile bookkeeping runs on the SALU (the FUSE1 build is out of SGPRs and keeps it per lane)
-    const int grp = FUSE1 ? (int)(threadIdx.x >> 8) : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    // wave group 0 / 1; scalar so that the tile bookkeeping runs on the SALU
+    const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;      // indices inside the group
     const int g = lane >> 4, p = lane & 15;
     const int total_tiles = tilesX * tilesY * B;
@@ -519,117 +511,6 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
         }
     };
 
-    // ---- FUSE1: conv1 of the next tile's halo image ----
-    constexpr int STG = 326;                         // bf16 per wave: [3 c][3 rows][36] + a zero + pad
-    if constexpr (FUSE1) {
-        if (lane == 0) (reinterpret_cast<bf16_t*>(in_lds + 2 * IN_BYTES + 256) + wave * STG)[324] = f32_to_bf16(0.f);
-    }
-    const int c1rows = wave < 2 ? 3 : 2;             // halo rows wave, wave + 4, wave + 8 (< HALO_H = 10)
-    auto conv1_load = [&](int tile, float (&v)[3][6], bf16x8 (&w1f)[4], f32x4 (&b1v)[4]) {
-        int t = tile;
-        const int tx = t % tilesX; t /= tilesX;
-        const int ty = t % tilesY;
-        const int b = t / tilesY;
-        // 32-bit element offsets from the image's (wave-uniform) base pointer: one address register per load (B*3*H*W < 2^31
-        // is checked by the entry point); element idx = lane + 64 u of the [3 c][3 rows][36] window of halo row wave + 4 rr
-        // everything below is loop-invariant per lane or per kernel (weights, bias, offsets) and LICM would hoist it out of the
-        // phase loop into registers that stay live across the K loop (which has none to spare: +93 spilled); laundering the
-        // lane index and the pointers through empty asm keeps it inside the phase
-        int ln = lane;
-        const bf16_t* w1q = w1;
-        const float* b1q = b1;
-        asm volatile("" : "+v"(ln), "+s"(w1q), "+s"(b1q));
-        const float* xb = x3 + (size_t)b * 3 * H * W;
-        const int y0 = ty * TH - 2 + wave, x0 = tx * TW - 2;
-        const bool interior = ty * TH >= 2 && ty * TH + TH + 2 <= H && tx * TW >= 2 && tx * TW + TW + 2 <= W;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int idx = ln + 64 * u;
-            const int c = idx / 108, rem = idx - c * 108, dyr = rem / 36, col = rem - dyr * 36;
-            const bool live = idx < 324;
-            const int lrel = live ? (c * H + dyr) * W + col : 0;
-#pragma unroll
-            for (int rr = 0; rr < 3; ++rr) {
-                float val = 0.f;
-                if (rr < c1rows) {
-                    const int iy = y0 + 4 * rr + dyr, ix = x0 + col;
-                    const bool ok = live && (interior || (iy >= 0 && iy < H && ix >= 0 && ix < W));
-                    const int off = ok ? (y0 + 4 * rr) * W + x0 + lrel : 0;
-                    val = xb[off];
-                    if (!ok) val = 0.f;
-                }
-                v[rr][u] = val;
-            }
-        }
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            w1f[ct] = *reinterpret_cast<const bf16x8*>(w1q + (ct * 16 + (ln & 15)) * 32 + 8 * (ln >> 4));
-            b1v[ct] = *reinterpret_cast<const f32x4*>(b1q + (ln >> 4) * 16 + ct * 4);
-        }
-    };
-    auto conv1_compute = [&](int tile, float (&v)[3][6], bf16x8 (&w1f)[4], f32x4 (&b1v)[4]) {
-        int t = tile;
-        const int tx = t % tilesX; t /= tilesX;
-        const int ty = t % tilesY;
-        // (recomputed per tile: nothing of conv1 stays live across the other phase's K loop, which runs at 243 registers)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int g = ln >> 4, p = ln & 15;           // (shadow the kernel's: see conv1_load)
-        bf16_t* stg = reinterpret_cast<bf16_t*>(in_lds + 2 * IN_BYTES + 256) + wave * STG;
-        // gather offsets of this lane's eight K values (k >= 27: any finite element -- zeroed after the read); pixel px = 16 gq + p
-        // is "+ p" in the base and an immediate 32 gq bytes: all 24 reads of a row are requested before the first is used
-        int koff1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = min(8 * g + j, 26), tap = k / 3, c = k - tap * 3, dy = tap / 3, dx = tap - dy * 3;
-            koff1[j] = c * 108 + dy * 36 + dx + p;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 3; ++rr) {
-            if (rr >= c1rows) break;
-            const int yy = wave + 4 * rr, iy = ty * TH - 1 + yy;
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const int idx = ln + 64 * u;
-                if (idx < 324) stg[idx] = f32_to_bf16(v[rr][u]);
-            }
-            bf16x8 pf[3];
-#pragma unroll
-            for (int gq = 0; gq < 3; ++gq)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[gq][j] = stg[koff1[j] + 16 * gq];       // (columns >= 36 of group 2: discarded below)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int gq = 0; gq < 3; ++gq) {
-                const int px = 16 * gq + p;
-                u32x4 pw = __builtin_bit_cast(u32x4, pf[gq]);
-                if (g == 3) { pw[1] &= 0xffffu; pw[2] = 0u; pw[3] = 0u; }             // k = 27 .. 31
-                f32x4 a1[4];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) a1[ct] = mfma16x16x32(w1f[ct], __builtin_bit_cast(bf16x8, pw), b1v[ct]);
-                const int ix = tx * TW - 1 + px;
-                const bool inside = iy >= 0 && iy < H && ix >= 0 && ix < W;
-                typedef short s16x2 __attribute__((ext_vector_type(2)));
-                uint32_t pk[8];
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    pk[ct * 2 + 0] = pack_bf16x2(a1[ct][0], a1[ct][1]);
-                    pk[ct * 2 + 1] = pack_bf16x2(a1[ct][2], a1[ct][3]);
-                }
-#pragma unroll
-                for (int w = 0; w < 8; ++w) {        // ReLU on the packed pairs (negative bf16 = negative int16), zero outside the image
-                    pk[w] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[w]), s16x2{0, 0}));
-                    pk[w] = inside ? pk[w] : 0u;
-                }
-                if (px < HALO_W) {                   // lane (g, p): channels 16 g .. 16 g + 15 of halo pixel q = two 16-byte chunks
-                    const int q = yy * HALO_W + px;
-                    *reinterpret_cast<u32x4*>(my_in + swz128(q, 2 * g)) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-                    *reinterpret_cast<u32x4*>(my_in + swz128(q, 2 * g + 1)) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-                }
-            }
-        }
-    };
-
     // tiles of this workgroup; group `grp` takes every second one.  XCD-contiguous bands (blockIdx & 7 = XCD, see
     // bra_rows_persistent_kernel): neighbouring tiles' shared halo stays in one L2.
     int first, first0, stride, limit;
@@ -669,16 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
             }
             bias_lds[threadIdx.x] = bval;
         }
-        if constexpr (FUSE1) {
-            __syncthreads();        // the staging lines' zero slots
-            if (grp == 0 && my_count > 0) {
-                float v[3][6]; bf16x8 w1f[4]; f32x4 b1v[4];
-                conv1_load(first, v, w1f, b1v);
-                conv1_compute(first, v, w1f, b1v);
-            }
-        } else {
-            if (grp == 0 && my_count > 0) prefetch_tile(c_first);
-        }
+        if (grp == 0 && my_count > 0) prefetch_tile(c_first);
         __syncthreads();            // weights + group 0's first tile visible (the barrier's vmcnt(0) retires the DMA)
         // c_done = the tile this group computed last (to be stored), c_next = the one to fetch next
         TC c_done = c_first, c_next = c_first;
@@ -699,18 +571,6 @@ __global__ __launch_bounds__(512, 2) void conv_c64_persistent_kernel(
                 // (computed tile k-1 in phase ph-1, next is k)
                 const int done = grp == 0 ? k : k - 1;
                 const int nxt = done + 1;
-                if constexpr (FUSE1) {
-                    // the 3-channel input of the next tile is requested first and lands under the stores of the finished one;
-                    // the accumulators' registers are free for conv1 once those stores are issued
-                    float v[3][6]; bf16x8 w1f[4]; f32x4 b1v[4];
-                    const bool have_next = nxt < my_count;
-                    if (have_next) conv1_load(first + nxt * stride, v, w1f, b1v);
-                    if (done >= 0 && done < my_count) store_tile(decode(first + done * stride), nt);
-                    if (have_next) conv1_compute(first + nxt * stride, v, w1f, b1v);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    continue;
-                }
                 // DMA first: it then has the whole phase (the other group's K loop) to land; the buffer is idle
                 // because this group's own K loop ended before the last barrier
                 if (nxt < my_count && !(stamps & 8)) prefetch_tile(c_next);
@@ -755,8 +615,12 @@ int launch_persistent(const void* x, const void* wp, const float* bias, const vo
     const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
     // bit 0: s_memtime stamps; bit 1: round-robin tiles instead of XCD bands; timing experiments (wrong results): TUP_CONV_ABLATE
     // bits 4 = no stores, 8 = no DMA, 16 = no K loop
+#ifdef TUP_DIAG          // `make diag` only; the product library always passes 0
     static const int conv_stamps_on = (getenv("TUP_CONV_STAMPS") ? 1 : 0) | (getenv("TUP_CONV_NO_XCD_BANDS") ? 2 : 0) |
                                       (getenv("TUP_CONV_ABLATE") ? (atoi(getenv("TUP_CONV_ABLATE")) & 28) : 0);
+#else
+    constexpr int conv_stamps_on = 0;
+#endif
     conv_c64_persistent_kernel<CT, OUT_MODE, KS><<<dim3(grid), dim3(512), lds, s>>>(
         (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)add, (const bf16_t*)mask, out, B, H, W, ntiles, r,
         cout_valid, relu, tilesX, tilesY, conv_stamps_on);
@@ -1161,23 +1025,6 @@ int launch_thin_rows(const void* x, const void* wp, const float* bias, float* ou
     return 0;
 }
 
-int launch_conv1_conv2(const float* x3, const void* w1, const float* b1, const void* wp, const float* bias, void* out,
-                       int B, int H, int W, hipStream_t s)
-{
-    constexpr int NPIX_HALO = (TH + 2) * (TW + 2);
-    constexpr size_t lds = (size_t)9 * 64 * 128 + 2 * (size_t)NPIX_HALO * 128 + 256 + 4 * 326 * 2 + 64;    // + bias + staging lines + pad
-    static_assert(lds <= 163840, "LDS budget");
-    TUP_SET_DYN_LDS((conv_c64_persistent_kernel<4, OUT_NHWC_BF16, 3, true>), lds);
-    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
-    const long long nt = (long long)tilesX * tilesY * B;
-    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const int grid = (int)(nt < 256 ? nt : 256);
-    conv_c64_persistent_kernel<4, OUT_NHWC_BF16, 3, true><<<dim3(grid), dim3(512), lds, s>>>(
-        nullptr, (const bf16_t*)wp, bias, nullptr, nullptr, out, B, H, W, 1, 1, 64, 1, tilesX, tilesY, 0, x3, (const bf16_t*)w1, b1);
-    TUP_CHECK_LAUNCH();
-    return 0;
-}
-
 // Border fix-up of the composed branch-A conv (see tup_conv5x5_c64_planar_fwd): one wave per HR border
 // pixel recomputes it with the weight variant that leaves out the 64->3 conv's taps falling outside
 // the HR image (those see zero padding in the reference, not a virtual up-conv value).
@@ -1290,18 +1137,6 @@ extern "C" int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* b
     return 0;
 }
 
-// conv1 + ReLU + conv2 + ReLU (reference model.py:251-252) in one kernel, inference: x3 fp32 [B][3][H][W]; w1 bf16 [64][32]
-// and b1 fp32 [64] as tup_conv3x3_c3_fwd takes them; wp bf16 [1][1][9][64][64] and bias fp32 [64] as tup_conv3x3_c64_fwd takes
-// them; out bf16 NHWC [B][H][W][64] = relu(conv2(relu(conv1(x3)))) with conv1's output rounded to bf16 exactly as the two-kernel
-// path rounds it.
-extern "C" int tup_conv1_conv2_fwd(const float* x3, const void* w1, const float* b1, const void* wp, const float* bias,
-                                   void* out, int B, int H, int W, void* stream)
-{
-    if (B <= 0 || H <= 0 || W <= 0) return 0;
-    if ((long long)B * 3 * H * W >= (1LL << 31)) return (int)hipErrorInvalidValue;
-    return launch_conv1_conv2(x3, w1, b1, wp, bias, out, B, H, W, reinterpret_cast<hipStream_t>(stream));
-}
-
 // Composed branch A for inference: Upsampler's last conv (64 -> 64*r*r, +bias), PixelShuffle(r) and
 // up1_conv (64 -> 3, no bias, ReLU) (reference utils.py:62-63,74-75,83-84 + utils.py:32-40, called at
 // model.py:264-265) have no non-linearity between them, so they are ONE linear map from the 64-channel LR
@@ -1352,8 +1187,10 @@ extern "C" int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const f
     return 0;
 }
 
-// Timing experiments only: the s_memtime stamps of the last launch under TUP_CONV_STAMPS=1 (2 groups x 16 phases x 5).
+#ifdef TUP_DIAG
+// Timing experiments only (`make diag`): the s_memtime stamps of the last launch under TUP_CONV_STAMPS=1 (2 groups x 16 phases x 5).
 extern "C" int tup_debug_conv_stamps(unsigned long long* host_out)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_conv_stamps), sizeof(unsigned long long) * 2 * 16 * 5);
 }
+#endif

@@ -746,7 +746,11 @@ BlockTable one_block(const float* g1, const float* b1n, const void* wh, const fl
 }
 int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* stream)
 {
-    static const bool stamps = getenv("TUP_B32_STAMPS") != nullptr;          // diagnostic build (timing shares only)
+#ifdef TUP_DIAG
+    static const bool stamps = getenv("TUP_B32_STAMPS") != nullptr;          // `make diag` only (timing shares)
+#else
+    constexpr bool stamps = false;
+#endif
     // launches of at most 512 windows (the chip's workgroup slots: 256 CUs x 2) run ONE window per workgroup, 16 token rows per wave:
     // twice the workgroups, half the serial work per wave -- the 720p -> 4K overlay frame (240 windows) 1.237 -> 1.166 ms; config 4's
     // 540 windows would be 1.05 rounds that way (2.59 vs 2.56 ms) and stay on the two-window form.  TUP_BLOCK_ONE_WINDOW=0 / 1 forces a form.
@@ -757,9 +761,11 @@ int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* str
     if (one_window && !stamps) {
         TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, false, 1>), FB_LDS);
         fused_qkv_attn_kernel<true, true, false, 1><<<dim3(nwin), dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
+#ifdef TUP_DIAG
     } else if (stamps) {
         TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true, true>), FB_LDS);
         fused_qkv_attn_kernel<true, true, true><<<grid, dim3(256), FB_LDS, s>>>(x, nullptr, nwin, x, t, nblk);
+#endif
     } else {
         TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
         // wave priority of every second resident set (see the kernel's first lines); TUP_BLOCK_PRIO=0 switches it off
@@ -838,8 +844,10 @@ extern "C" int tup_fused_blocks32_fwd(float* x, const void* const* table, int nb
     return launch_blocks32(x, t, nblk, nwin, stream);
 }
 
-// Timing experiments only: per-phase cycle sums of the last TUP_B32_STAMPS=1 launch, [8 workgroups][4 waves][16 phases].
+#ifdef TUP_DIAG
+// Timing experiments only (`make diag`): per-phase cycle sums of the last TUP_B32_STAMPS=1 launch, [8 workgroups][4 waves][16 phases].
 extern "C" int tup_debug_block32_stamps(unsigned long long* host_out)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_b32_stamps), sizeof(unsigned long long) * 8 * 4 * NPH32);
 }
+#endif

@@ -337,9 +337,12 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
         hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<OCC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e; \
         tail_fused_kernel<OCC, ST><<<grid, dim3(NT), lds, reinterpret_cast<hipStream_t>(stream)>>>(p); } while (0)
+#ifdef TUP_DIAG          // `make diag` only
     if (stamps_on && occ2) TUP_TAIL_LAUNCH(2, true);      // spill-free stamps (the <4, true> build spills 143 VGPRs: its shares mislead)
     else if (stamps_on) TUP_TAIL_LAUNCH(4, true);
-    else if (occ2) TUP_TAIL_LAUNCH(2, false);
+    else
+#endif
+    if (occ2) TUP_TAIL_LAUNCH(2, false);
     else if (occ3) TUP_TAIL_LAUNCH(3, false);
     else TUP_TAIL_LAUNCH(4, false);
 #undef TUP_TAIL_LAUNCH
@@ -347,8 +350,10 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     return 0;
 }
 
-// Timing experiments only: s_memtime stamps of the last launch under TUP_TAIL_STAMPS=1 (9 values).
+#ifdef TUP_DIAG
+// Timing experiments only (`make diag`): s_memtime stamps of the last launch under TUP_TAIL_STAMPS=1 (9 values).
 extern "C" int tup_debug_tail_stamps(unsigned long long* host_out)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tup_tail_stamps), sizeof(unsigned long long) * 16);
 }
+#endif

@@ -40,18 +40,19 @@ struct TailStreamParams {
 
 // Neighbour exchange by DPP wave shifts, as volatile asm: the values are fetched where they are used (a handful of transient
 // registers); as intrinsics hipcc hoists every exchange of a stage to its top and spills.  hipcc does not see into the asm, so
-// the VALU-write -> DPP-read hazard (2 wait states) is the caller's: hipcc sinks the instruction that defines a value down to its
-// first use, i.e. right in front of the exchange (found as wrong first rows of every band).  Every X / T value is therefore pinned
-// by an empty volatile asm where it is produced, a whole weight group (>= 3 ds_read + 1 s_waitcnt + 6 packed FMAs) or more
-// before its first exchange.
+// the VALU-write -> DPP-read hazard (2 wait states) is handled INSIDE the asm: `s_nop 1` in front of the DPP move, whatever hipcc
+// schedules ahead of it (hipcc sinks the instruction that defines a value down to its first use, i.e. right in front of the
+// exchange: found as wrong first rows of every band; rounds 3's fix pinned the producers a weight group earlier, which held only
+// as long as hipcc kept that order).  The pins stay (they keep the nops from ever waiting); tests/test_hip_kernels.py checks the
+// band seams.
 TUP_DEVICE float from_left(float v) {     // lane l <- lane l - 1 (0 into lane 0)
     float r;
-    asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
     return r;
 }
 TUP_DEVICE float from_right(float v) {    // lane l <- lane l + 1 (0 into lane 63)
     float r;
-    asm volatile("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v));
     return r;
 }
 

@@ -48,9 +48,6 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
 
 
 blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
-# inference: conv1 + conv2 in one kernel (tup_conv1_conv2_fwd).  OFF by default: bit-identical to the two kernels, but at 8 x 720p
-# 0.92 ms against their 0.73 ms (the VALU work of conv1 in the idle wave group comes out of the K loop's MFMA issue)
-fuse_conv12 = bool(os.environ.get("TUP_FUSE_CONV12"))
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
@@ -111,14 +108,10 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
     cap = capture
     x = x.contiguous().float()
     B, _, H, W = x.shape
-    if fuse_conv12 and cap is None:
-        with _stage("conv2"):                      # conv1 + ReLU + conv2 + ReLU in one kernel: conv1's output never exists in HBM
-            feat = ops.conv1_conv2(x, pk["conv1.w"], pk["conv1.b"], pk["conv2.w"], pk["conv2.b"])
-    else:
-        feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
-        with _stage("conv2"):
-            feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
-        del feat1
+    feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
+    with _stage("conv2"):
+        feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
+    del feat1
     # branch A: Upsampler + up1_conv (conv, no bias, ReLU)
     stages = upsampler_layout(scale)
     up = feat
@@ -159,7 +152,8 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
         for si, (_, r) in enumerate(fu[:-1]):
             t = ops.conv_planar(t, pk[f"fu.{si}.w"], pk[f"fu.{si}.b"], r)
         li = len(fu) - 1
-        if stream_tail and fu[li][1] == 2 and "tail.wfu_t" in pk:
+        if (stream_tail and fu[li][1] == 2 and "tail.wfu_t" in pk
+                and ops.tail_stream_fits(t.shape[0], t.shape[2], t.shape[3], tuple(res_out) if needs_resize else None)):
             with _stage("tail"):
                 out = ops.tail_stream_r2(t, pk["tail.wfu_t"], pk[f"fu.{li}.b"], pk["tail.wfc_t"], pk["fuc.b"], upscaled_input,
                                          clamp=True, out_hw=tuple(res_out) if needs_resize else None)

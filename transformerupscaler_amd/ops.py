@@ -91,16 +91,6 @@ def conv1(x, wp, bias, relu=True, in_mask=None, out_mask=None):
     return out
 
 
-def conv1_conv2(x, w1, b1, wp, bias):
-    """conv1 + ReLU + conv2 + ReLU in one kernel (inference): planar fp32 [B][3][H][W] -> NHWC bf16 [B][H][W][64]."""
-    B, C, H, W = x.shape
-    assert C == 3
-    out = torch.empty((B, H, W, 64), dtype=BF16, device=x.device)
-    _lib.call("tup_conv1_conv2_fwd", _chk(x, F32, None, "x"), _chk(w1, BF16, (64, 32), "w1"), _chk(b1, F32, (64,), "b1"),
-              _chk(wp, BF16, (1, 1, 9, 64, 64), "wp"), _chk(bias, F32, (1, 64), "bias"), out.data_ptr(), B, H, W, _stream())
-    return out
-
-
 def conv_c64(x, wp, bias, r=1, relu=False, add=None, mask=None, in_r=1):
     """NHWC bf16 conv 64*in_r^2 -> 64*r*r with fused PixelShuffle(r); returns [B][H*r][W*r][64] bf16.
     x is [B][H*in_r][W*in_r][64] (in_r > 1: channels read through PixelShuffle^-1)."""
@@ -236,6 +226,17 @@ def _tail_stream_plan(device, B, H, W, Ho, Wo):
                 plan = (t(ylo), t(yn), t(yw), ky, t(xlo), t(xn), t(xw), kx, t(oxb), t(oyb), sc, bh, ext)
         _TAP_CACHE[key] = plan
     return _TAP_CACHE[key]
+
+
+def tail_stream_fits(B, H, W, out_hw=None):
+    """The streaming tail addresses its tensors with 32-bit byte offsets: tup_tail_stream_r2_fwd refuses B*12*H*W >= 2^29 elements
+    (the HR map of the last stage), tup_tail_stream_r2_resize_fwd also B*3*Ho*Wo >= 2^29 (csrc/tail_stream.hip).  Batches beyond that
+    (4x of 720p from B = 13, 540p -> 2160p from B = 22) take the tiled tail (tail_fused), which has no such limit."""
+    if B * 12 * H * W >= 1 << 29:
+        return False
+    if out_hw is not None and tuple(out_hw) != (2 * H, 2 * W) and B * 3 * int(out_hw[0]) * int(out_hw[1]) >= 1 << 29:
+        return False
+    return True
 
 
 def tail_stream_r2(x, wfu_t, bfu, wfc_t, bfc, ui, clamp=True, out_hw=None):
@@ -687,7 +688,17 @@ def rt_patch_unembed(x, wt, bias, skip):
     return out
 
 
+def _rt_dropout_check(N, drop_p):
+    # the attention-probability mask decides two neighbouring keys per hash and a lane holds four consecutive keys (csrc/common.h
+    # drop_pair4): the kernels take dropout only on token counts that are multiples of 4 (the reference's 720 x 1280 input = 3600
+    # tokens, models/ResidualTransformer/model.py:135-140); p is quantised to multiples of 1 / 65536
+    if drop_p > 0.0 and N % 4 != 0:
+        raise ValueError(f"ResidualTransformer attention dropout needs a token count that is a multiple of 4 (got N = {N}); "
+                         "call .eval() or use an input whose token grid has a multiple of 4 tokens")
+
+
 def rt_attention(qkv, B, N, save_lse=False, drop_p=0.0, drop_seed=0):
+    _rt_dropout_check(N, drop_p)
     out = torch.empty((B * N, 128), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, 8, N), dtype=F32, device=qkv.device) if save_lse else None
     _lib.call("tup_rt_attention_fwd", _chk(qkv, BF16, (B * N, 384), "qkv"), out.data_ptr(),
@@ -696,6 +707,7 @@ def rt_attention(qkv, B, N, save_lse=False, drop_p=0.0, drop_seed=0):
 
 
 def rt_attention_bwd(qkv, out, gout, lse, B, N, drop_p=0.0, drop_seed=0):
+    _rt_dropout_check(N, drop_p)
     gqkv = torch.empty((B * N, 384), dtype=BF16, device=qkv.device)
     work = torch.empty((B, 8, N), dtype=F32, device=qkv.device)
     _lib.call("tup_rt_attention_bwd", _chk(qkv, BF16, (B * N, 384), "qkv"), _chk(out, BF16, (B * N, 128), "out"),

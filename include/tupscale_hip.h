@@ -420,6 +420,13 @@ int tup_resize_u8_cols(const void* src, void* dst_u8, float* dst_f32, const int*
  * tup_fused_block_fwd after x in that order and packing. */
 int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
 
+/* The same loop (model.py:288-289; blocks :153-172) as the streamed 32x32x16-MFMA kernel (csrc/block_stream.hip): one workgroup of
+ * eight waves carries four windows through all nblk blocks; LayerNorm / softmax / GELU instructions sit between the matrix
+ * instructions of the same wave.  x fp32 [64*nwin][192] in place; table: HOST array [nblk][7] of device pointers, per block the
+ * tensors of packing.pack_stream_block: wqk bf16 [12][3][32][64], wv bf16 [6][3][32][64], wproj bf16 [6][3][32][64],
+ * w1 bf16 [24][3][32][64], w2 fp16 [24][6][32][32], tab fp32 [1536], sbias fp32 [12][2][2][64][16]. */
+int tup_blocks_stream_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
+
 /* Re-packing the weights after an optimizer step (training; replaces the torch index / permute / cat / cast calls of
  * packing.py that follow reference train.py:139 `optimizer.step()`): dst[i] = map[i] < 0 ? 0 : concat(src[0..nparam-1])[map[i]].
  * src: device array of nparam device pointers to the fp32 parameters; offs: device int [nparam + 1] prefix sum of their sizes;

@@ -792,3 +792,49 @@ def test_branch_a_composed_training(dev, B, H, W):
     fr = rel(dfeat.permute(0, 3, 1, 2)[..., frame], feat.grad[..., frame])
     assert max(r_f, fr) <= 2e-2, (r_f, fr)
     assert r_u <= 2e-2 and r_b <= 2e-2 and r_3 <= 2e-2, (r_u, r_b, r_3)
+
+
+def _stream_operands(dev, raw):
+    from transformerupscaler_amd import packing
+    return tuple(t.to(dev) for t in packing.pack_stream_block(raw["w"], raw["b"], raw["gm1"], raw["bt1"], raw["table"], raw["wp"], raw["bp"],
+                                                              raw["w1"], raw["b1"], raw["gm2"], raw["bt2"], raw["w2"], raw["b2"]))
+
+
+@pytest.mark.parametrize("nwin", [1, 3, 4, 5, 64, 1920])
+def test_stream_block_vs_torch(dev, nwin):
+    """tup_blocks_stream_fwd (the streamed 32x32x16 whole-block kernel, model.py:153-172) with one block against torch fp32 on
+    bf16-rounded GEMM operands, and against the 16x16x32 whole-block kernel; 1, 3, 5 exercise the inactive waves of the four-window
+    workgroup, 1920 = one launch of BASELINE configs[1]."""
+    from transformerupscaler_amd import ops
+    raw, args = _block_operands(dev, nwin)
+    x = raw["x"].to(dev)
+    got = ops.blocks_stream(x.clone(), ops.stream_table([_stream_operands(dev, raw)]))
+    assert torch.isfinite(got).all()
+    ref = _block_torch(raw, nwin)
+    e = (got.cpu() - ref).abs().max().item()
+    b32 = ops.fused_block(x.clone(), *args)
+    d = (got - b32).abs()
+    print(f"nwin {nwin}: stream vs torch {e:.3e} (|ref| max {ref.abs().max().item():.2f}); vs the 16x16x32 kernel max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    assert e <= 3e-2 + 1e-2 * ref.abs().max().item(), e
+    assert d.max().item() <= 4e-2 and d.mean().item() <= 6e-3
+    assert (got - x).abs().max().item() > 0.1
+
+
+def test_stream_blocks_six_in_one_launch(dev):
+    """Six blocks (three weight sets, cycled) in one launch of the streamed kernel against six one-block launches of it (the residual
+    stream carried in registers across blocks, the LDS regions handed from block to block) and against the 16x16x32 kernel."""
+    from transformerupscaler_amd import ops
+    nwin = 37
+    sets = [_block_operands(dev, nwin, seed=40 + i) for i in range(3)]
+    st = [_stream_operands(dev, s[0]) for s in sets]
+    x = _block_operands(dev, nwin, seed=50)[0]["x"].to(dev)
+    one = ops.blocks_stream(x.clone(), ops.stream_table([st[i % 3] for i in range(6)]))
+    seq = x.clone()
+    for i in range(6):
+        ops.blocks_stream(seq, ops.stream_table([st[i % 3]]))
+    assert torch.isfinite(one).all()
+    assert torch.equal(one, seq)
+    ref = ops.fused_blocks32(x.clone(), ops.block_table([tuple(sets[i % 3][1]) for i in range(6)]))
+    d = (one - ref).abs()
+    print(f"six blocks: stream vs 16x16x32 kernel max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    assert d.max().item() <= 0.15 and d.mean().item() <= 1.5e-2

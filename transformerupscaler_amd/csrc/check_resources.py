@@ -20,6 +20,7 @@ import sys
 # (source file, kernel function names) -> every instantiation must have ScratchSize == 0
 GUARDED = [
     ("fused_attn.hip", ["fused_qkv_attn_kernel"]),
+    ("block_stream.hip", ["blocks_stream_kernel"]),
     ("fused_blocks.hip", ["fused_mlp_v2_kernel"]),
     ("conv3x3_c64.hip", ["conv_c64_persistent_kernel", "bra_rows_persistent_kernel", "conv3_thin_rows_kernel"]),
     ("conv_thin.hip", ["conv3x3_c3_persistent_kernel"]),
@@ -27,7 +28,7 @@ GUARDED = [
 ]
 # diagnostic template instantiations, never launched by the product path: fused_qkv_attn_kernel<PROJ, MLP, STAMPS = true>, the
 # timing ablations fused_mlp_v2_kernel<ABL != 0>
-EXEMPT = re.compile(r"fused_qkv_attn_kernel<true, true, true>|fused_qkv_attn_kernelILb1ELb1ELb1E|fused_mlp_v2_kernelILi[1-9]")
+EXEMPT = re.compile(r"fused_qkv_attn_kernel<true, true, true>|fused_qkv_attn_kernelILb1ELb1ELb1E|fused_mlp_v2_kernelILi[1-9]|blocks_stream_kernel<true>|blocks_stream_kernelILb1E")
 # Known spills that sit OUTSIDE the counted hand-off (checked in the ISA): allowed up to the recorded size, so growth still fails.
 #  * conv_c64_persistent_kernel<4,0,3>: two per-lane source pointers of the first tile's prefetch, spilled at kernel entry and
 #    reloaded once per cout pass BEFORE that pass's first DMA -- older than every DMA piece a counted wait covers;

@@ -48,6 +48,11 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
 
 
 blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
+# inference: the one launch is the streamed 32x32x16 kernel (csrc/block_stream.hip); TUP_BLOCKS_16X16=1 = round 3's 16x16x32 kernel (A/B)
+stream_blocks = not os.environ.get("TUP_BLOCKS_16X16")
+# the streamed kernel's workgroup carries four windows (one workgroup per CU): launches that would leave most CUs without one stay on the
+# 16x16x32 kernel, whose small-launch form runs one window per workgroup (the 720p -> 4K overlay frame: 240 windows; config 4: 540)
+STREAM_MIN_WINDOWS = int(os.environ.get("TUP_STREAM_MIN_WINDOWS", "512"))
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
@@ -61,6 +66,11 @@ def _block_operands(pk, i, bias_frags):
 
 def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
     """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
+    if (fuse_blocks and fuse_attention >= 3 and capture is None and "b0.stream.0" in pk and blocks_in_one_launch and stream_blocks
+            and x.shape[0] // 64 >= STREAM_MIN_WINDOWS):
+        # all six blocks in ONE launch of the streamed kernel (csrc/block_stream.hip)
+        table = ops.stream_table([tuple(pk[f"b{i}.stream.{j}"] for j in range(7)) for i in range(BLOCKS)])
+        return ops.blocks_stream(x, table)
     if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and blocks_in_one_launch:
         # all six blocks in ONE launch (csrc/fused_attn.hip)
         table = ops.block_table([_block_operands(pk, i, bias_frags) for i in range(BLOCKS)])

@@ -383,6 +383,32 @@ def fused_blocks32(x, table):
     return x
 
 
+def stream_table(blocks):
+    """Pointer table for tup_blocks_stream_fwd: per block the 7 tensors of packing.pack_stream_block (wqk, wv, wproj, w1, w2, tab,
+    sbias), validated here.  Returns (ctypes array, nblk, the tensors -- kept alive by the caller holding the tuple)."""
+    import ctypes
+    shapes = [(BF16, 12 * 6144), (BF16, 6 * 6144), (BF16, 6 * 6144), (BF16, 24 * 6144), (F16, 24 * 6144), (F32, 1536), (F32, 12 * 2 * 2 * 64 * 16)]
+    if not 1 <= len(blocks) <= 8:
+        raise ValueError("1..8 blocks per launch")
+    ptrs = []
+    for blk in blocks:
+        assert len(blk) == 7
+        for i, (t, (dt, n)) in enumerate(zip(blk, shapes)):
+            if t.numel() != n:
+                raise ValueError(f"stream block operand {i}: {t.numel()} elements, expected {n}")
+            ptrs.append(_chk(t, dt, None, f"stream block operand {i}"))
+    return ((ctypes.c_void_p * len(ptrs))(*ptrs), len(blocks), [list(b) for b in blocks])
+
+
+def blocks_stream(x, table):
+    """In place: the table's consecutive WindowTransformerBlocks in one launch of the streamed 32x32x16 kernel (csrc/block_stream.hip)."""
+    M = x.shape[0]
+    assert M % 64 == 0
+    arr, nblk, _keep = table
+    _lib.call("tup_blocks_stream_fwd", _chk(x, F32, (M, 192), "x"), arr, nblk, M // 64, _stream())
+    return x
+
+
 def fused_block(x, wh, bh, bias_frag, wproj, bproj, w1, b1, w2, b2):
     """In place: one whole WindowTransformerBlock (attention half + MLP half) in one kernel (inference fusion).  Operands as the
     rows of block_table: LayerNorm scale / shift folded into wh / bh and w1 / b1 (packing.fold_layernorm)."""

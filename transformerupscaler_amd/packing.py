@@ -172,6 +172,123 @@ def pack_proj_pairs(weight: torch.Tensor):
     return perm_rows64(weight.detach()[:, idx.to(weight.device)]).contiguous().to(torch.bfloat16)
 
 
+# ---- the streamed whole-block kernel (csrc/block_stream.hip, tup_blocks_stream_fwd): 32x32x16 MFMA tiles ----
+# A wave owns 32 tokens (lane r = l & 31, half h = l >> 5).  An accumulator tile [32 rows][32 tokens] keeps row
+# rho(i, h) = (i & 3) + 8 (i >> 2) + 4 h in register i of a lane.  The residual stream uses six such tiles with tile row rho of tile rt
+# = channel 32 rt + 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3), so that a lane's 16 registers of a tile are 16 consecutive channels
+# (64-byte loads / stores of x) and pack pairwise into the B fragments of the product that follows a LayerNorm: K-step s = 2 rt + u,
+# half h, element j  <->  channel 32 rt + 16 h + 8 u + j.
+def _stream_rho(i, h):
+    return (i & 3) + 8 * (i >> 2) + 4 * h
+
+
+def _stream_out_channel():
+    """tile row (rt, rho) -> residual channel, [192]"""
+    rho = torch.arange(32)
+    ch = 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3)
+    return (torch.arange(6).view(6, 1) * 32 + ch.view(1, 32)).reshape(-1)
+
+
+def _stream_k_after_ln():
+    """packed K column kappa = 16 s + 8 h + j -> residual channel (the order in which LayerNorm's fragments hold the channels)"""
+    k = torch.arange(192)
+    s_, h, j = k // 16, (k % 16) // 8, k % 8
+    return 32 * (s_ // 2) + 16 * h + 8 * (s_ % 2) + j
+
+
+def _stream_k_acc(n):
+    """packed K column kappa = 16 s + 8 h + j -> row 16 s + rho(j, h) of an accumulator tile that is the B operand (n columns)"""
+    k = torch.arange(n)
+    s_, h, j = k // 16, (k % 16) // 8, k % 8
+    return 16 * s_ + (j & 3) + 8 * (j >> 2) + 4 * h
+
+
+def _stream_image192(t: torch.Tensor) -> torch.Tensor:
+    """[n][32 rows][192 K] (bf16 / fp16) -> the byte-exact LDS image [n][3 k-tiles][32][64]: 128-byte rows whose 16-byte chunk c sits at
+    position c ^ ((row >> 1) & 7) (conflict-free ds_read_b128 of the 32x32x16 A fragments; the DMA is then a linear copy)."""
+    n = t.shape[0]
+    v = t.reshape(n, 32, 3, 8, 8).permute(0, 2, 1, 3, 4)                 # [n][kt][row][chunk][8]
+    row = torch.arange(32).view(32, 1)
+    pos = torch.arange(8).view(1, 8)
+    src = (pos ^ ((row >> 1) & 7)).view(1, 1, 32, 8, 1).expand(n, 3, 32, 8, 8).to(t.device)
+    return torch.gather(v, 3, src).contiguous()
+
+
+def _stream_image32(t: torch.Tensor) -> torch.Tensor:
+    """[n][32 rows][32 K] -> LDS image with 64-byte rows, chunk c at position c ^ ((row >> 2) & 3)."""
+    n = t.shape[0]
+    v = t.reshape(n, 32, 4, 8)
+    row = torch.arange(32).view(32, 1)
+    pos = torch.arange(4).view(1, 4)
+    src = (pos ^ ((row >> 2) & 3)).view(1, 32, 4, 1).expand(n, 32, 4, 8).to(t.device)
+    return torch.gather(v, 2, src).contiguous()
+
+
+def _bf16_hi_lo_words(v: torch.Tensor) -> torch.Tensor:
+    """fp32 -> int32 words  bf16(v) | bf16(v - bf16(v)) << 16  (the two K columns of a bias K-step: v to 2^-17 relative)."""
+    hi = v.to(torch.bfloat16)
+    lo = (v - hi.float()).to(torch.bfloat16)
+    w = hi.view(torch.int16).to(torch.int32) & 0xFFFF | (lo.view(torch.int16).to(torch.int32) << 16)
+    return w.contiguous()
+
+
+def relpos_bias_matrix(table: torch.Tensor) -> torch.Tensor:
+    """relative_position_bias_table [225][heads] -> bias [heads][64 queries][64 keys] (model.py:89-100,120-124) for 8 x 8 windows."""
+    ys, xs = torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij")
+    ys, xs = ys.flatten(), xs.flatten()
+    idx = ((ys[:, None] - ys[None, :] + 7) * 15 + (xs[:, None] - xs[None, :] + 7)).to(table.device)
+    return table.detach().float()[idx.view(-1)].view(64, 64, -1).permute(2, 0, 1).contiguous()
+
+
+def pack_stream_block(wqkv, bqkv, gamma1, beta1, table, wproj, bproj, w1, b1, gamma2, beta2, w2, b2):
+    """One WindowTransformerBlock (model.py:153-172; heads 12 x 16, dim 192, hidden 768) for tup_blocks_stream_fwd.  Returns the seven
+    tensors of a table row: wqk bf16 [12][3][32][64] (per head a tile of 16 q rows, pre-scaled by head_dim^-0.5 log2(e), model.py:117,
+    and 16 k rows), wv bf16 [6][3][32][64] (per head pair 16 + 16 v rows), wproj bf16 [6][3][32][64], w1 bf16 [24][3][32][64]
+    (mlp.0 / 4 in chunks of 32 hidden units), w2 fp16 [24][6][32][32] (4 mlp.2), tab fp32 [1536] (qk biases [12][2][16], mlp.0 biases
+    [24][2][16], bias K-step words of proj [6][32] and mlp.2 [6][32]), sbias fp32 [12][2][2][64][16] (relative position bias as the
+    accumulator input of S^T).  LayerNorm scale / shift are folded into attn.qkv / mlp.0 (fold_layernorm); the v bias goes through the
+    softmax (rows of P sum to 1) and the proj, so it is folded into the proj bias."""
+    dev = wqkv.device
+    wq, bq = fold_layernorm(wqkv, bqkv, gamma1, beta1)                  # fp32 [576][192], [576]
+    w1f, b1f = fold_layernorm(w1, b1, gamma2, beta2)
+    kln = _stream_k_after_ln().to(dev)
+    wq = wq[:, kln]
+    # q carries head_dim^-0.5 (model.py:117) AND log2(e): the scores come out in log2 units and the kernel's softmax is exp2(s - max)
+    LOG2E = 1.4426950408889634
+    q = wq[0:192].reshape(12, 16, 192) * (0.25 * LOG2E)
+    k = wq[192:384].reshape(12, 16, 192)
+    v = wq[384:576].reshape(6, 32, 192)
+    wqk = _stream_image192(torch.cat([q, k], dim=1).to(torch.bfloat16))
+    wv = _stream_image192(v.to(torch.bfloat16))
+    och = _stream_out_channel().to(dev)
+    wp_b = wproj.detach().float().to(torch.bfloat16)
+    wp = wp_b[och][:, _stream_k_acc(192).to(dev)].reshape(6, 32, 192)
+    wpi = _stream_image192(wp)
+    w1c = (w1f[:, kln] * 0.25).reshape(24, 32, 192).to(torch.bfloat16)
+    w1i = _stream_image192(w1c)
+    w2p = (w2.detach().float() * 4.0)[och][:, _stream_k_acc(768).to(dev)]            # [192][768]: columns in chunks of 32
+    w2c = w2p.reshape(6, 32, 24, 32).permute(2, 0, 1, 3).reshape(24 * 6, 32, 32).to(torch.float16)
+    w2i = _stream_image32(w2c).reshape(24, 6, 32, 32)
+    # tables
+    i = torch.arange(16)
+    rho = torch.stack([_stream_rho(i, 0), _stream_rho(i, 1)])                        # [2][16]
+    qb = (bq[0:192].reshape(12, 16) * (0.25 * LOG2E))
+    kb = bq[192:384].reshape(12, 16)
+    qkb = torch.cat([qb, kb], dim=1)[:, rho.to(dev)]                                  # [12][2][16]
+    b1t = (b1f * 0.25).reshape(24, 32)[:, rho.to(dev)]                                # [24][2][16]
+    bp = bproj.detach().float() + wp_b.float() @ bq[384:576]                          # v bias through softmax and proj
+    tab = torch.cat([qkb.reshape(-1), b1t.reshape(-1),
+                     _bf16_hi_lo_words(bp[och]).view(torch.float32), _bf16_hi_lo_words(b2.detach().float()[och]).view(torch.float32)])
+    assert tab.numel() == 384 + 768 + 192 + 192
+    # relative position bias as S^T accumulator tiles: [head][query half][key half][lane][16]: key 32 KT + rho(i, l >> 5), query 32 hf + (l & 31)
+    bias = relpos_bias_matrix(table) * LOG2E                                          # [12][q][k], log2 units
+    lane = torch.arange(64)
+    qi = (torch.arange(2).view(2, 1, 1, 1) * 32 + (lane & 31).view(1, 1, 64, 1)).expand(2, 2, 64, 16)
+    ki = (torch.arange(2).view(1, 2, 1, 1) * 32 + _stream_rho(i.view(1, 1, 1, 16), (lane >> 5).view(1, 1, 64, 1))).expand(2, 2, 64, 16)
+    sb = bias[:, qi.to(dev), ki.to(dev)].contiguous()                                 # [12][2][2][64][16]
+    return (wqk.contiguous(), wv.contiguous(), wpi.contiguous(), w1i.contiguous(), w2i.contiguous(), tab.contiguous().float(), sb)
+
+
 def pack_patch_embed(weight: torch.Tensor):
     """Conv2d(64,192,k8,s8) weight [192][64][8][8] -> bf16 [192][4096], k = (i*8+j)*64 + c."""
     return pack_linear(weight.permute(0, 2, 3, 1).reshape(192, 4096))
@@ -308,6 +425,13 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], scale: int, backward: bool = Fa
             pk[f"b{i}.fc1.wfqn"], pk[f"b{i}.fc1.bqn"] = pack_fc1_fused_q(*fold_layernorm(
                 sd[f"{p}.mlp.0.weight"], sd[f"{p}.mlp.0.bias"], sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"]))
             pk[f"b{i}.fc2.wh4"] = pack_fc2_h4(sd[f"window_blocks.{i}.mlp.2.weight"])
+            # the streamed 32x32x16 whole-block kernel (csrc/block_stream.hip)
+            for j, t in enumerate(pack_stream_block(
+                    sd[f"{p}.attn.qkv.weight"], sd[f"{p}.attn.qkv.bias"], sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"],
+                    sd[f"{p}.attn.relative_position_bias_table"], sd[f"{p}.attn.proj.weight"], sd[f"{p}.attn.proj.bias"],
+                    sd[f"{p}.mlp.0.weight"], sd[f"{p}.mlp.0.bias"], sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"],
+                    sd[f"{p}.mlp.2.weight"], sd[f"{p}.mlp.2.bias"])):
+                pk[f"b{i}.stream.{j}"] = t
     pk["pu.w"] = pack_patch_unembed(sd["patch_unembed.weight"].detach()); pk["pu.b"] = f32(sd["patch_unembed.bias"])
     pk["dec1.w"], pk["dec1.b"] = pack_conv_c64(sd["decoder_conv1.weight"].detach(), sd["decoder_conv1.bias"].detach(), 1)
     pk["dec2.w"] = pack_conv_c64_thin(sd["decoder_conv2.weight"].detach()); pk["dec2.b"] = f32(sd["decoder_conv2.bias"])

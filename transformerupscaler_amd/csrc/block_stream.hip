@@ -166,41 +166,45 @@ template <int K0, int K1> TUP_DEVICE void softmax_ops(SmState& st, f32x16 (&S)[2
     static_for<(K1 > K0 ? K1 - K0 : 0)>([&](auto k) { softmax_op<K0 + decltype(k)::value>(st, S, P, h0); });
 }
 
-// ---- GELU of a hidden chunk (16 accumulator values per lane = 8 fp16 pairs) as 88 micro-operations: two batches of four chains ----
-// (the polynomial of common.h gelu16_batch: x' = x / 4 in, gelu(x) / 4 out).  op 44 b + k: k < 4 convert pair k; then step-major:
-// k = 4 + 4 t + i, step t < 10 of chain i (t = 0: the clamp, two instructions).
+// ---- GELU of a hidden chunk (16 accumulator values per lane = 8 fp16 pairs) as 80 micro-operations: two batches of four chains ----
+// (the form of common.h gelu16_batch: x' = x / 4 in, gelu(x) / 4 = x' (0.5 + xc R(xc^2 - 0.5)) out, xc = clamp(x', +-1), with R of
+// degree FIVE here: every vector instruction of this kernel costs its issue slot beside the MFMAs (the GELU arithmetic is 90 of the
+// launch's 790 us, timing build TUP_BSX_NOGELU), and in fp16 arithmetic the degree-5 fit -- same constraints, pinned tail -- is as good as
+// the degree-6 one: max |error| 4.2e-3 vs 3.9e-3 (the fp16 rounding of the Horner chain, not the fit), rms 7.3e-4 vs 4.6e-4 under
+// N(0, 1.5); the bf16 hidden tile of rounds 1-2 had 1.6e-2 / 2.4e-3.)  op 40 b + k: k < 4 convert pair k; then step-major:
+// k = 4 + 4 t + i, step t < 9 of chain i (t = 0: the clamp, two instructions).
 // Pinning: hipcc sinks a chain nothing in its slot consumes out of the MFMA stream (a GELU phase of its own in the loop latch;
 // sched_barrier binds only the machine scheduler), so the four results of a step pass through ONE empty volatile asm behind the
 // step's last operation.  (One asm per result cost an s_nop each -- hipcc pads a packed instruction that follows an inline asm --
 // and an asm between the conversion and the clamp a canonicalising v_pk_max per value: 47 + 32 instructions per pair of slots.)
-constexpr int GELU_OPS = 88;
+constexpr int GELU_OPS = 80;
 struct GeluState { h2 x[4], xc[4], sv[4], q[4]; };
 #define TUP_PIN4(A) asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]))
 template <int K> TUP_DEVICE void gelu_op(GeluState& g, const f32x16& acc, bf16x8 (&hf)[2]) {
-    constexpr int b = K / 44, k = K % 44;
+    constexpr int b = K / 40, k = K % 40;
     const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
     if constexpr (k < 4) {
         g.x[k] = __builtin_convertvector(f32x2{acc[8 * b + 2 * k], acc[8 * b + 2 * k + 1]}, h2);
     } else {
         constexpr int t = (k - 4) >> 2, i = (k - 4) & 3;
-        constexpr float C[5] = {1.54543088f, -1.13520344f, 0.88632128f, -0.6753973f, 0.70388307f};
+        constexpr float C[4] = {-1.28229402f, 0.86809017f, -0.66956203f, 0.70398137f};
         if constexpr (t == 0) g.xc[i] = __builtin_elementwise_min(__builtin_elementwise_max(g.x[i], -one), one);
         else if constexpr (t == 1) g.sv[i] = __builtin_elementwise_fma(g.xc[i], g.xc[i], h2{(_Float16)-0.5f, (_Float16)-0.5f});
-        else if constexpr (t == 2) g.q[i] = __builtin_elementwise_fma(g.sv[i], h2{(_Float16)1.51615563f, (_Float16)1.51615563f}, h2{(_Float16)-2.11659751f, (_Float16)-2.11659751f});
-        else if constexpr (t < 8) g.q[i] = __builtin_elementwise_fma(g.q[i], g.sv[i], h2{(_Float16)C[t - 3], (_Float16)C[t - 3]});
-        else if constexpr (t == 8) g.q[i] = __builtin_elementwise_fma(g.xc[i], g.q[i], h2{(_Float16)0.5f, (_Float16)0.5f});
+        else if constexpr (t == 2) g.q[i] = __builtin_elementwise_fma(g.sv[i], h2{(_Float16)-1.43921925f, (_Float16)-1.43921925f}, h2{(_Float16)1.90463124f, (_Float16)1.90463124f});
+        else if constexpr (t < 7) g.q[i] = __builtin_elementwise_fma(g.q[i], g.sv[i], h2{(_Float16)C[t - 3], (_Float16)C[t - 3]});
+        else if constexpr (t == 7) g.q[i] = __builtin_elementwise_fma(g.xc[i], g.q[i], h2{(_Float16)0.5f, (_Float16)0.5f});
         else g.x[i] = g.x[i] * g.q[i];
     }
 }
 // the pins of the steps that operation K completes (issued by the caller behind the gap's LDS requests: a pin directly behind a
 // packed instruction whose result it names costs an s_nop as well)
 template <int K> TUP_DEVICE void gelu_pin(GeluState& g, bf16x8 (&hf)[2]) {
-    constexpr int b = K / 44, k = K % 44;
+    constexpr int b = K / 40, k = K % 40;
     if constexpr (k >= 4 && ((k - 4) & 3) == 3) {
         constexpr int t = (k - 4) >> 2;
         if constexpr (t == 0) TUP_PIN4(g.xc);
         else if constexpr (t == 1) TUP_PIN4(g.sv);
-        else if constexpr (t < 9) TUP_PIN4(g.q);
+        else if constexpr (t < 8) TUP_PIN4(g.q);
         else {
             TUP_PIN4(g.x);
             u32x4 pk;
@@ -674,33 +678,51 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
                 constexpr int n = decltype(n_)::value;
                 constexpr bool is1 = F1 && (!F2 || (n & 1) == 0);
                 constexpr int k = (F1 && F2) ? n / 2 : n;
+#ifdef TUP_BSX_NOLDS          // timing experiment (wrong results): the MLP slots without their LDS fragment reads
+                return __builtin_bit_cast(bf16x8, u32x4{a1[k & 3], a2[k & 1], (uint32_t)n, 0u});
+#else
                 if constexpr (is1) return lds_read_b128_asm_off(a1[k & 3], (k >> 2) * 4096);
                 else return lds_read_b128_asm_off(a2[k & 1], (k >> 1) * 2048);
+#endif
             };
-            bf16x8 wq[4];
+            // fragments LA MFMAs ahead (ring of LA + 1): with eight waves reading 1 KB per MFMA the LDS runs half busy and a read takes
+            // longer than the three gaps the attention loops allow
+            constexpr int LA = 5, RS = LA + 1;
+            bf16x8 wq[RS];
             f32x4 b0, b1, b2, b3;
             if constexpr (F1) { b0 = lds_read_f4_off(tb, 0); b1 = lds_read_f4_off(tb, 16); b2 = lds_read_f4_off(tb, 32); b3 = lds_read_f4_off(tb, 48); }
-            wq[0] = frag(std::integral_constant<int, 0>{}); wq[1] = frag(std::integral_constant<int, 1>{}); wq[2] = frag(std::integral_constant<int, 2>{});
-            lds_wait<2>();
+            static_for<LA>([&](auto i_) { wq[decltype(i_)::value] = frag(i_); });
+            lds_wait<LA - 1>();
             FENCE();
             if constexpr (F1) acc1[PAR] = acc_from4(b0, b1, b2, b3);
             static_for<NM>([&](auto n_) {
                 constexpr int n = decltype(n_)::value;
                 constexpr bool is1 = F1 && (!F2 || (n & 1) == 0);
                 constexpr int k = (F1 && F2) ? n / 2 : n;
-                if constexpr (is1) acc1[PAR] = mfma32(wq[n & 3], tf[k], acc1[PAR]);
-                else R[k >> 1] = mfma32h(wq[n & 3], hfr[PAR][k & 1], R[k >> 1]);
+                if constexpr (is1) acc1[PAR] = mfma32(wq[n % RS], tf[k], acc1[PAR]);
+                else R[k >> 1] = mfma32h(wq[n % RS], hfr[PAR][k & 1], R[k >> 1]);
+                // Order of a gap: the MFMA; the pins of the PREVIOUS gap's GELU results (an asm right behind the packed instruction whose
+                // result it names, or right in front of one that reads it, costs an s_nop); the LDS request; the wait; this gap's GELU work
+#ifndef TUP_BSX_NOGELU
+                if constexpr (GE && n > 0) gelu_pins<(GELU_OPS * (n - 1)) / NM, (GELU_OPS * n) / NM>(gs, hfr[1 - PAR]);
+#endif
+                if constexpr (n + LA < NM) wq[(n + LA) % RS] = frag(std::integral_constant<int, n + LA>{});
+                if constexpr (n + 1 < NM) lds_wait<(NM - 2 - n < LA - 1 ? NM - 2 - n : LA - 1)>();
+#ifndef TUP_BSX_NOGELU        // timing experiment (wrong results): ... without the GELU arithmetic (fc1's accumulators kept alive)
                 if constexpr (GE) gelu_ops<(GELU_OPS * n) / NM, (GELU_OPS * (n + 1)) / NM>(gs, acc1[1 - PAR], hfr[1 - PAR]);
+#else
+                if constexpr (GE && n == NM - 1) { asm volatile("" :: "v"(acc1[1 - PAR])); asm volatile("" : "+v"(hfr[1 - PAR][0]), "+v"(hfr[1 - PAR][1])); }
+#endif
+#ifndef TUP_BSX_NODMA         // ... without the weight DMA requests (stale weights)
                 if constexpr (DM && n % (NM / 12) == NM / 12 - 1) {
                     constexpr int pi = n / (NM / 12);
                     if constexpr (pi < 6) dma_chunk_piece(c + 2, d0, pi); else dma_chunk_piece(c + 3, d1, pi - 6);
                 }
+#endif
                 if constexpr (LNS && n >= 4) ln_stats_ops<16 * (n & 1), 16 * (n & 1) + 16>(ln1, R[(n - 4) >> 1]);
-                // (the inline-asm reads come LAST in the gap, in front of the next MFMA: hipcc pads a vector instruction that directly follows
-                // an inline asm with register results by an s_nop -- 2.5 per gap when the read stood between the MFMA and the GELU work)
-                if constexpr (n + 3 < NM) wq[(n + 3) & 3] = frag(std::integral_constant<int, n + 3>{});
-                if constexpr (n + 1 < NM) lds_wait<(NM - 2 - n < 2 ? NM - 2 - n : 2)>();
-                if constexpr (GE) gelu_pins<(GELU_OPS * n) / NM, (GELU_OPS * (n + 1)) / NM>(gs, hfr[1 - PAR]);
+#ifndef TUP_BSX_NOGELU
+                if constexpr (GE && n == NM - 1) gelu_pins<(GELU_OPS * n) / NM, GELU_OPS>(gs, hfr[1 - PAR]);
+#endif
                 FENCE();
             });
             BS_STAMP(Q_MLP);

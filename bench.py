@@ -15,10 +15,12 @@ gradient reducer report (ranks, backend, buckets, bytes all-reduced per step).
 Inference shards by images with no data-path collective (replicas, weak scaling).  Prints ONE JSON
 line on rank 0 (contract in the task statement).  ``roofline`` describes the kernel with the largest
 total time per forward, decided live from event timings on the launch stream: the whole-block kernel
-``fused_qkv_attn_kernel<true,true>`` (one launch per WindowTransformerBlock, 6 per forward; algorithmic
-FLOPs = the window-attention GEMM set of SURVEY 8(d), 86.1 GF per image / 6) or the 64->64 3x3
+(round 4: ``blocks_stream_kernel``, the six WindowTransformerBlocks of a forward in one launch; algorithmic
+FLOPs = the window-attention GEMM set of SURVEY 8(d), 86.1 GF per image) or the 64->64 3x3
 implicit-GEMM conv (conv2 + decoder_conv1, 2 launches per forward); the other one is reported as
-``roofline_second``.  ``cpu_baseline`` = the oracle (CPU restatement of the reference, "port") on a
+``roofline_second`` -- since round 4 the two convs together (0.85 ms) outweigh the block launch (0.78 ms), so the
+window-attention GEMM set, north_star's 0.40 target, is the SECOND entry.  ``sustained`` = the same forward loop
+for >= 2 s after the timed steps with the shader clock it held.  ``cpu_baseline`` = the oracle (CPU restatement of the reference, "port") on a
 bounded sample: forward, forward+backward (train.py:117-140), and the PSNR of the build's output
 against the oracle's output for the same image (``psnr_vs_ref_db``, plus ΔPSNR against a synthetic HR).
 """
@@ -122,10 +124,13 @@ def rt_cpu_baseline():
             "sample": f"{n} forward+backward passes of 1 image 720x1280 -> 4320x7680 fp32 (L1 loss, dropout off) after 1 warm-up"}
 
 
+PROFILE_ROUND = "r04"          # the committed counter runs the line quotes (profiles/<round>_pmc_*.json)
+
+
 def pmc_traffic(kernel_key: str, mode: str = "infer"):
     """HBM bytes per launch from the committed PMC run of this round, or None when the kernel's source changed since
     (the JSON records the sha256 of the .hip file it was measured on; a stale number is worse than none)."""
-    name = f"r03_pmc_traffic_{mode}.json"
+    name = f"{PROFILE_ROUND}_pmc_traffic_{mode}.json"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             pm = json.load(f)
@@ -140,10 +145,10 @@ def pmc_traffic(kernel_key: str, mode: str = "infer"):
 
 
 def pmc_mfma(kernel_key: str):
-    """Counter-based matrix-pipe utilisation of the committed PMC run (profiles/r03_pmc_mfma.json): SQ_VALU_MFMA_BUSY_CYCLES over
+    """Counter-based matrix-pipe utilisation of the committed PMC run (profiles/<round>_pmc_mfma.json): SQ_VALU_MFMA_BUSY_CYCLES over
     every SIMD-cycle of the launch (rocprof's MfmaUtil expression) and the clock the chip held, or None when stale / absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_mfma.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_mfma.json")) as f:
             ent = json.load(f)[kernel_key]
         with open(os.path.join(ROOT, "transformerupscaler_amd", "csrc", ent["source"]), "rb") as f:
             if hashlib.sha256(f.read()).hexdigest() != ent["source_sha256"]:
@@ -151,7 +156,7 @@ def pmc_mfma(kernel_key: str):
         d = ent["derived"]
         return {"mfma_util": d.get("mfma_util"), "clock_GHz": d.get("clock_GHz_from_GRBM_GUI_ACTIVE"),
                 "wait_any_share": d.get("sq_wait_any_share_of_wave_cycles"), "issue_stall_share": d.get("sq_wait_inst_any_share_of_wave_cycles"),
-                "source": "profiles/r03_pmc_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ..., own pass)"}
+                "source": f"profiles/{PROFILE_ROUND}_pmc_mfma.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ..., own pass)"}
     except Exception:          # noqa: BLE001
         return None
 
@@ -523,6 +528,31 @@ def main():
     timing_on[0] = False
     assert tuple(y.shape) == (args.batch, 3) + OUT
 
+    # What the hardware sustains: the same loop for >= 2 s, OUTSIDE the headline number (the 20 timed steps are 0.07 s, a stretch in
+    # which the chip still holds its boost clock).  The shader clock of the stretch = shader cycles / 100 MHz ticks between two one-wave
+    # probes in stream order (MI355X_MICROARCH.md, 'DVFS give-back' item 6).
+    sustained = None
+    if rank == 0:
+        from transformerupscaler_amd import ops as _ops
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            p0 = _ops.clock_probe()
+            ts, n_sus = time.perf_counter(), 0
+            while True:
+                for _ in range(20):
+                    y = model(x, res_out=OUT)
+                n_sus += 20
+                torch.cuda.synchronize()
+                if time.perf_counter() - ts >= 2.0:
+                    break
+            p1 = _ops.clock_probe()
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+        dcy, dtk = int(p1[0] - p0[0]), int(p1[1] - p0[1])
+        sustained = {"seconds": dts, "steps": n_sus, "images_per_sec": args.batch * n_sus / dts, "ms_per_step": dts / n_sus * 1e3,
+                     "clock_GHz": (dcy / dtk * 0.1) if dtk > 0 else None,
+                     "clock_source": "s_memtime / s_memrealtime between two one-wave probes around the loop (tup_clock_probe)"}
+
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -536,20 +566,27 @@ def main():
     attn_tf = ATTN_SET_FLOP_PER_IMAGE * args.batch / (blocks_ms * 1e-3) / 1e12 if blocks_ms > 0 else 0.0
     conv_tf = CONV64_FLOP_PER_IMAGE * args.batch / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     nwin = args.batch * 12 * 20                    # 96x160 token grid -> 12 x 20 windows per 720p image
-    blk_traffic, blk_src = pmc_traffic("fused_block")
     conv_traffic, conv_src = pmc_traffic("conv64")
     if args.batch != 8:
-        blk_traffic = conv_traffic = None
+        conv_traffic = None
+    streamed = bool(_engine.stream_blocks and n_block_launch == 1 and nwin >= _engine.STREAM_MIN_WINDOWS)
+    blk_key = "stream_block" if streamed else "fused_block"
+    blk_traffic, blk_src = pmc_traffic(blk_key)
+    if args.batch != 8:
+        blk_traffic = None
     roof_block = {"bound": "mfma",
-                  "kernel": "fused_qkv_attn_kernel<true,true> (whole WindowTransformerBlocks: norm1 + qkv + window attention + proj + residual + "
+                  "kernel": ("blocks_stream_kernel (csrc/block_stream.hip, v_mfma_f32_32x32x16; " if streamed else "fused_qkv_attn_kernel<true,true> (") +
+                            "whole WindowTransformerBlocks: norm1 + qkv + window attention + proj + residual + "
                             "norm2 + fc1 + GELU + fc2 + residual; " + ("the 6 blocks of a forward in ONE launch)" if n_block_launch == 1
                                                                        else "one block per launch, 6 launches per forward)"),
                   "blocks_per_launch": 6 // n_block_launch, "ms_per_block": blocks_ms / 6,
                   "achieved": attn_tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": attn_tf / MFMA_BF16_PEAK_TFLOPS,
-                  "traffic": blk_traffic, "traffic_source": blk_src, "counters": pmc_mfma("fused_block"),
+                  "traffic": blk_traffic, "traffic_source": blk_src, "counters": pmc_mfma(blk_key),
                   "algorithmic_flop_per_launch": ATTN_SET_FLOP_PER_IMAGE * args.batch / n_block_launch,
                   # SURVEY 8(d)'s per-block figure (the fp32 residual stream read once + written once) x the blocks one launch runs
                   "algorithmic_bytes": nwin * 64 * 192 * 4 * 2 * (6 // n_block_launch),
+                  # ... and what ONE launch of six blocks needs at the least: the stream in once and out once, the weights once
+                  "algorithmic_bytes_one_launch_minimum": nwin * 64 * 192 * 4 * 2 + 6 * 885 * 1024,
                   "ms_per_launch": blk_ms, "total_ms_per_forward": blocks_ms, "launches_timed": len(block_events) * n_block_launch,
                   "note": "algorithmic FLOPs = SURVEY 8(d)'s window-attention GEMM set (qkv, QK^T, PV, proj, fc1, fc2 = 86.1 GF per image); "
                           "LayerNorm / softmax / GELU run inside the same launches and are not counted; north_star target frac >= 0.40"}
@@ -576,10 +613,14 @@ def main():
                        "weights": "deterministic synthetic (transformerupscaler_amd.weights, seed 0)"},
             "roofline": dominant,
             "roofline_second": second,
+            "sustained": sustained,
         }
         out["build"] = build_info()
         if train_result is not None:
             out["train"] = train_result
+            # the number north_star's ">= 6x at 8 GPUs" is about, at the top level next to the replica-inference `value`
+            out["train_images_per_sec"] = train_result.get("value")
+            out["train_ms_per_step"] = train_result.get("ms_per_step")
             if train_result.get("rccl") is not None:
                 out["rccl"] = train_result["rccl"]          # the FastTransformer training step's reducer (configs[2])
         if rt_result is not None:

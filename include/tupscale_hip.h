@@ -355,6 +355,10 @@ int tup_wt_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, 
 int tup_l1_loss_partial(const float* a, const float* b, float* partial, long long n, int nblocks, void* stream);
 int tup_l1_loss_bwd(const float* a, const float* b, const float* gout, float* ga, long long n, void* stream);
 
+/* Measurement aid (bench.py `sustained.clock_GHz`; no reference counterpart): writes s_memtime (shader cycles) and s_memrealtime
+ * (100 MHz ticks) of one wave to out2[0], out2[1] (two uint64 on the device), in stream order. */
+int tup_clock_probe(void* out2, void* stream);
+
 /* WindowTransformer backward pieces: the FastTransformer entries for `heads` = 8 or 12 and the window-layout patch weight
  * gradient on the floor(H/8) x floor(W/8) token grid (out fp32 [NI][4096] += P^T patches(map), no reflect padding). */
 int tup_relpos_bias_expand_n_h(const float* table, float* frag, int heads, void* stream);

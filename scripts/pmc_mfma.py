@@ -2,9 +2,9 @@
 """Counter-based MFMA evidence for the whole-block kernel (SURVEY 8(d) "rocprof MFMA utilisation").
 
 Joins rocprofv3 --pmc passes (each collected in its own run with --kernel-trace only) of
-`bench.py --steps 3 --warmup 1 --mode infer --no-cpu-baseline` into profiles/r03_pmc_mfma.json:
+`bench.py --steps 3 --warmup 1 --mode infer --no-cpu-baseline` into profiles/r04_pmc_mfma.json:
 
-    python scripts/pmc_mfma.py <out_json> <stats_csv> <pmc_dir> [<pmc_dir> ...]
+    python scripts/pmc_mfma.py <out_json> <stats_csv> <pmc_dir> [<pmc_dir> ...] [--mode infer|train|rt]
 
 Per kernel of interest: the raw counter means per launch, and derived from them
   * mfma_util            = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)  -- rocprof's own `MfmaUtil` expression
@@ -17,12 +17,29 @@ import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {
-    "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip"),
-    "conv64": ("conv_c64_persistent_kernel<4, 0, 3, false>", "conv3x3_c64.hip"),
-    "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip"),
-    "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip"),
-    "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip"),
+KERNELS_BY_MODE = {
+    "infer": {
+        "stream_block": ("blocks_stream_kernel", "block_stream.hip"),
+        "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip"),
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip"),
+        "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip"),
+        "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip"),
+        "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip"),
+    },
+    "train": {   # FastTransformer training step (BASELINE configs[2] per rank)
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip"),
+        "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip"),
+        "gemm_wgrad": ("gemm_wgrad_kernel<0, 0>", "gemm_wgrad.hip"),
+        "bra_wgrad": ("bra_wgrad_kernel", "branch_a_train.hip"),
+        "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip"),
+        "window_attn_fwd": ("window_attn_kernel<12", "attention.hip"),
+        "fused_mlp": ("fused_mlp_v2_kernel", "fused_blocks.hip"),
+    },
+    "rt": {      # ResidualTransformer 6x training step (configs[4] per rank)
+        "rt_attn_fwd": ("rt_attention_kernel<true>", "rt_kernels.hip"),
+        "rt_attn_bwd_dq": ("rt_attn_bwd_dq_kernel<true>", "rt_kernels.hip"),
+        "rt_attn_bwd_dkv": ("rt_attn_bwd_dkv_kernel<true>", "rt_kernels.hip"),
+    },
 }
 SIMDS = 256 * 4
 
@@ -37,10 +54,15 @@ def counters(dirs):
 
 
 def main():
-    out, stats_csv, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    argv = list(sys.argv[1:])
+    mode = "infer"
+    if "--mode" in argv:
+        i = argv.index("--mode"); mode = argv[i + 1]; del argv[i:i + 2]
+    KERNELS = KERNELS_BY_MODE[mode]
+    out, stats_csv, dirs = argv[0], argv[1], argv[2:]
     acc = counters(dirs)
     dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(stats_csv))}
-    res = {"_note": "rocprofv3 --pmc <counters> --kernel-trace (each pass its own run) of `bench.py --steps 3 --warmup 1 --mode infer "
+    res = {"_note": "rocprofv3 --pmc <counters> --kernel-trace (each pass its own run) of `bench.py --steps 3 --warmup 1 --mode " + mode + " "
                     "--no-cpu-baseline`; values are means per launch; durations from the --kernel-trace --stats pass of the same command. "
                     "Profiled passes run at a lower clock than untraced ones (guide, DVFS item 2): read ratios, not absolute times."}
     for key, (sub, src) in KERNELS.items():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Join two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, guide MI355X_MICROARCH.md 'HBM') and a --kernel-trace
---stats pass of the same bench command into profiles/r03_pmc_traffic_<mode>.json: per kernel the HBM-side bytes per launch
+--stats pass of the same bench command into profiles/r04_pmc_traffic_<mode>.json: per kernel the HBM-side bytes per launch
 (FETCH_SIZE x 2 on gfx950 for wide coalesced reads + WRITE_SIZE, both reported in KB) and the rate at the traced duration.
 Each entry records the sha256 of the kernel's source file; bench.py reports `traffic` only while that still matches.
 
@@ -16,8 +16,10 @@ MB = 1e6
 F64 = 720 * 1280 * 64 * 2            # one 64-channel bf16 map of a 720p image
 KEYS = {
     "infer": {   # B = 8, 2x 720p -> 1080p
-        "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 1920 * 64 * 192 * 4 * 2),      # six blocks per launch
-        "conv64": ("conv_c64_persistent_kernel<4, 0, 3, false>", "conv3x3_c64.hip", 2 * 8 * F64),
+        # six blocks per launch.  Algorithmic bytes as SURVEY 8(d) counts them: the residual stream read + written per block; the launch's own
+        # minimum is the stream in once + out once + the weights (0.19 GB + 5.3 MB); the kernel parks the stream once per block
+        "stream_block": ("blocks_stream_kernel", "block_stream.hip", 6 * 1920 * 64 * 192 * 4 * 2),
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 8 * F64),
         "tail": ("tail_stream_r2_kernel<true>", "tail_stream.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
         "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", 1920 * 64 * 192 * 4 + 2 * 8 * F64),
         "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip", 8 * F64 + 1920 * 64 * 192 * 4),
@@ -27,12 +29,12 @@ KEYS = {
     },
     "x4": {      # B = 4, 4x 540p -> 2160p: the tail's last stage runs 1080p -> 2160p without a Resize
         "tail": ("tail_stream_r2_kernel<false>", "tail_stream.hip", 4 * 3 * (1080 * 1920 + 2 * 2160 * 3840) * 4),
-        "fused_block": ("fused_qkv_attn_kernel<true, true", "fused_attn.hip", 6 * 540 * 64 * 192 * 4 * 2),        # 4 x 135 windows
+        "stream_block": ("blocks_stream_kernel", "block_stream.hip", 6 * 540 * 64 * 192 * 4 * 2),        # 4 x 135 windows
         "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip", 4 * 1080 * 1920 * 64 * 2 + 4 * 3 * 2160 * 3840 * 4),
     },
     "train": {   # B = 4, 2x 720p -> 1080p training step
         "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 2 * 192 * 2 + 576 * 2) + 960 * 12 * 64 * 4),      # qkv, d att, att, lse in; d qkv out
-        "conv64": ("conv_c64_persistent_kernel<4, 0, 3, false>", "conv3x3_c64.hip", 2 * 4 * F64),
+        "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 4 * F64),
         "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip", 2 * 4 * F64),
         "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),          # only when H or W is not a multiple of 8
         "pe_bwd_merge": ("gemm_panel2_kernel<1, 6>", "gemm_tokens.hip", 960 * 64 * 192 * 4 + 4 * 4 * F64),      # tokens in; two adds, the gate map in, the merged gradient out

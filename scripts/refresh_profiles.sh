@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the round's committed evidence on the MI355X box (run through gpurun from the repo root, one part per call):
-#   part a:  profiles/r03_kernel_stats_{infer,train,rt,x4}.csv   rocprofv3 --kernel-trace --stats of bench.py per mode
-#            profiles/r03_grid_rounds_{train,rt}.txt             scripts/grid_rounds.py on the same traces
-#            profiles/r03_pmc_mfma.json                           two --pmc passes (matrix-pipe / wave-cycle counters) joined by scripts/pmc_mfma.py
-#   part b:  profiles/r03_pmc_traffic_{infer,x4,train,rt}.json    two --pmc passes per mode (FETCH_SIZE, WRITE_SIZE) joined by scripts/pmc_traffic.py
+#   part a:  profiles/r04_kernel_stats_{infer,train,rt,x4}.csv   rocprofv3 --kernel-trace --stats of bench.py per mode
+#            profiles/r04_grid_rounds_{train,rt}.txt             scripts/grid_rounds.py on the same traces
+#            profiles/r04_pmc_mfma{,_train,_rt}.json              two --pmc passes (matrix-pipe / wave-cycle counters) joined by scripts/pmc_mfma.py
+#   part b:  profiles/r04_pmc_traffic_{infer,x4,train,rt}.json    two --pmc passes per mode (FETCH_SIZE, WRITE_SIZE) joined by scripts/pmc_traffic.py
 # Counters are collected in their own runs (--pmc with --kernel-trace only).  Outputs land in gpurun_out/refresh/; copy them to profiles/.
 set -e
 part=${1:-a}
@@ -15,8 +15,8 @@ if [ "$part" = a ]; then
   for m in infer train rt x4; do
     rm -rf $O/stats_$m
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -- python3 bench.py --steps 10 --warmup 3 --mode $m --no-cpu-baseline > $O/stats_$m.log 2>&1
-    cp $(ls $O/stats_$m/*/*kernel_stats.csv | head -1) $O/r03_kernel_stats_$m.csv
-    python3 scripts/grid_rounds.py $O/stats_$m 200 > $O/r03_grid_rounds_$m.txt 2>&1 || true
+    cp $(ls $O/stats_$m/*/*kernel_stats.csv | head -1) $O/r04_kernel_stats_$m.csv
+    python3 scripts/grid_rounds.py $O/stats_$m 200 > $O/r04_grid_rounds_$m.txt 2>&1 || true
     rm -rf $O/stats_$m
     echo "stats $m done"
   done
@@ -25,10 +25,19 @@ if [ "$part" = a ]; then
   echo "pmc a done"
   timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_TRANS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/pmc_b -- python3 bench.py --steps 3 --warmup 1 --mode infer --no-cpu-baseline > $O/pmc_b.log 2>&1
   echo "pmc b done"
-  python3 scripts/pmc_mfma.py $O/r03_pmc_mfma.json $O/r03_kernel_stats_infer.csv $O/pmc_a $O/pmc_b
+  python3 scripts/pmc_mfma.py $O/r04_pmc_mfma.json $O/r04_kernel_stats_infer.csv $O/pmc_a $O/pmc_b
   rm -rf $O/pmc_a $O/pmc_b
-  timeout -k 10 400 python3 bench.py > $O/r03_bench_default.json 2> $O/bench.err
-  tail -c 600 $O/r03_bench_default.json
+  # the same two passes for the training steps (VERDICT r3 missing #3: counter evidence outside inference)
+  for m in train rt; do
+    rm -rf $O/pmc_a $O/pmc_b
+    timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_a -- python3 bench.py --steps 3 --warmup 1 --mode $m --no-cpu-baseline > $O/pmc_a_$m.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_TRANS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/pmc_b -- python3 bench.py --steps 3 --warmup 1 --mode $m --no-cpu-baseline > $O/pmc_b_$m.log 2>&1
+    python3 scripts/pmc_mfma.py $O/r04_pmc_mfma_$m.json $O/r04_kernel_stats_$m.csv $O/pmc_a $O/pmc_b --mode $m
+    echo "pmc mfma $m done"
+  done
+  rm -rf $O/pmc_a $O/pmc_b
+  timeout -k 10 400 python3 bench.py > $O/r04_bench_default.json 2> $O/bench.err
+  tail -c 600 $O/r04_bench_default.json
 else
   for m in infer x4 train rt; do
     for c in FETCH_SIZE WRITE_SIZE; do
@@ -37,9 +46,9 @@ else
       echo "pmc $m $c done"
     done
     # durations: part a's stats of this mode (copied to profiles/ between the two calls: gpurun_out/ does not travel to the box)
-    python3 scripts/pmc_traffic.py $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE profiles/r03_kernel_stats_$m.csv $O/r03_pmc_traffic_$m.json $m
+    python3 scripts/pmc_traffic.py $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE profiles/r04_kernel_stats_$m.csv $O/r04_pmc_traffic_$m.json $m
     rm -rf $O/pmc_${m}_FETCH_SIZE $O/pmc_${m}_WRITE_SIZE
   done
 fi
-if [ "$part" = b ]; then timeout -k 10 120 python3 scripts/microbench_hbm.py > $O/r03_microbench_hbm.txt 2>&1; cat $O/r03_microbench_hbm.txt; fi
+if [ "$part" = b ]; then timeout -k 10 120 python3 scripts/microbench_hbm.py > $O/r04_microbench_hbm.txt 2>&1; cat $O/r04_microbench_hbm.txt; fi
 echo "refresh $part done"

@@ -121,9 +121,27 @@ def test_delta_psnr_vs_reference(model, golden_dir):
 
 
 # ---------------------------------------------------------------- training at 720p ----------------------------------------
-def _check_grads_vs_fixture(model, d, rel_full=0.10, samp=0.10, norm=0.05):
+def _grad_family(name: str) -> str:
+    """Parameter families whose gradient errors differ by nature (limits per family, not one global number)."""
+    if name.endswith("relative_position_bias_table"):
+        return "relpos_table"          # sums with near-total cancellation over windows (see the gate-matched test below)
+    if name.startswith("conv1.") or name.endswith(".bias") and not name.startswith("window_blocks."):
+        return "cnn_bias+conv1"        # sit behind the most ReLU / clamp gates that flip under bf16
+    if name.startswith("window_blocks."):
+        return "blocks"
+    return "cnn_weights"
+
+
+# Limits of the fixture comparison = the reference's own gradients (fp32) against this path's (bf16 operands, gates that flip):
+# (sampled max error / max |g|, norm error, full relative L2), per family.  Set from the values the 720p and crop fixtures measure on
+# the MI355X (printed by the test) times 1.3, rounded up; the calibration file (tests/golden/calib_bf16_autocast.json) puts the
+# reference's OWN bf16-autocast run at 6.6-7.9 % median / 9.4-24 % worst relative L2 on the same weights, i.e. above every limit here.
+GRAD_LIMITS = {"relpos_table": (0.11, 0.03, 0.11), "cnn_bias+conv1": (0.11, 0.03, 0.11), "blocks": (0.08, 0.02, 0.08), "cnn_weights": (0.08, 0.02, 0.08)}
+
+
+def _check_grads_vs_fixture(model, d):
     none = set(d["none_grads"].tolist()) if "none_grads" in d else set()
-    worst_s = worst_n = worst_f = 0.0
+    worst = {}
     for k, p in model.named_parameters():
         if k in none:
             assert p.grad is None, f"{k} must not receive a gradient"
@@ -133,15 +151,22 @@ def _check_grads_vs_fixture(model, d, rel_full=0.10, samp=0.10, norm=0.05):
         g = p.grad.detach().double().cpu().flatten()
         e_s = np.abs(g[torch.from_numpy(d["gidx_" + k])].float().numpy() - d["gval_" + k]).max() / max(st[2], 1e-12)
         e_n = abs(g.norm().item() - st[1]) / max(st[1], 1e-12)
-        worst_s, worst_n = max(worst_s, e_s), max(worst_n, e_n)
+        e_f = 0.0
         if "gfull_" + k in d:
             full = torch.from_numpy(d["gfull_" + k]).double().flatten()
-            rel = (g - full).norm().item() / max(full.norm().item(), 1e-12)
-            worst_f = max(worst_f, rel)
-            assert rel <= rel_full, f"{k}: relative L2 error {rel:.4f}"
-        assert e_s <= samp, f"{k}: sampled max err {e_s:.4f} of max|g|"
-        assert e_n <= norm, f"{k}: norm err {e_n:.4f}"
-    print(f"worst sampled {worst_s:.4f}, worst norm {worst_n:.4f}, worst full rel-L2 {worst_f:.4f}")
+            e_f = (g - full).norm().item() / max(full.norm().item(), 1e-12)
+        fam = _grad_family(k)
+        w = worst.setdefault(fam, [0.0, 0.0, 0.0, "", "", ""])
+        for i, e in enumerate((e_s, e_n, e_f)):
+            if e > w[i]:
+                w[i], w[3 + i] = e, k
+    for fam, w in sorted(worst.items()):
+        print(f"   {fam}: worst sampled {w[0]:.4f} ({w[3]}), worst norm {w[1]:.4f} ({w[4]}), worst full rel-L2 {w[2]:.4f} ({w[5]})")
+    for fam, w in worst.items():
+        ls, ln, lf = GRAD_LIMITS[fam]
+        assert w[0] <= ls, f"{fam} / {w[3]}: sampled max err {w[0]:.4f} of max|g| (limit {ls})"
+        assert w[1] <= ln, f"{fam} / {w[4]}: norm err {w[1]:.4f} (limit {ln})"
+        assert w[2] <= lf, f"{fam} / {w[5]}: relative L2 error {w[2]:.4f} (limit {lf})"
 
 
 def test_train_720p_grads_match_reference(det_sd, golden_dir):
@@ -242,17 +267,20 @@ def test_grads_mask_matched_vs_oracle(det_sd, scale, shape, kw):
     med = sorted(errs.values())[len(errs) // 2]
     worst = max(errs, key=errs.get)
     print(f"scale {scale} mask-matched: relative L2 median {med:.4f} worst {errs[worst]:.4f} ({worst})")
-    assert med <= 0.02, med
+    assert med <= 0.012, med                   # measured 0.0069-0.0076 over the five geometries
     # The relative-position tables are the one family whose gradient is a sum with almost complete cancellation (every row of
-    # dS sums to zero; the table entry collects dS over all windows and all (i, j) of one offset), so the bf16 rounding of the
-    # operands the backward is handed (qkv, d att) shows in it amplified.  At crop size they stay under the common 5 %; at
-    # 720p (240 windows) the worst measures 7.0 % and gets its own limit -- everything else is held to 5 % at every size.
+    # dS sums to zero; the table entry collects dS over all windows and all (i, j) of one offset).  The kernel accumulates dS in
+    # fp32 BEFORE any rounding (attention_bwd.hip: dbacc += ds), so what shows amplified is not the reduction but the one-sweep
+    # form of the softmax Jacobian: rowsum(P o dP) is taken as dO . O with the bf16 O (and the bf16-rounded P behind it) of the
+    # forward, which leaves every row of dS a small non-zero sum that does not cancel across windows.  The exact form needs a
+    # second sweep over the keys (or 64 more registers in a 470-register kernel): +0.1-0.2 ms per step, not taken.  At crop size the
+    # tables measure 3.9-4.9 %, at 720p (240 windows) 7.0-8.2 %; everything else 0.9-1.05 % at every size.
     tables = {k: v for k, v in errs.items() if k.endswith("relative_position_bias_table")}
     rest = {k: v for k, v in errs.items() if k not in tables}
     w_rest, w_tab = max(rest, key=rest.get), max(tables, key=tables.get)
     print(f"   worst outside the relative-position tables {rest[w_rest]:.4f} ({w_rest}); worst table {tables[w_tab]:.4f} ({w_tab})")
-    assert rest[w_rest] <= 0.05, (w_rest, rest[w_rest])
-    assert tables[w_tab] <= (0.10 if shape[2] >= 720 else 0.05), (w_tab, tables[w_tab])
+    assert rest[w_rest] <= 0.02, (w_rest, rest[w_rest])                      # measured <= 0.0105; was 0.05
+    assert tables[w_tab] <= (0.10 if shape[2] >= 720 else 0.065), (w_tab, tables[w_tab])
 
 
 # ---------------------------------------------------------------- caller patterns -----------------------------------------

@@ -62,6 +62,7 @@ SIGNATURES = {
     "tup_fused_block_fwd": [P] * 10 + [I, P],
     "tup_fused_blocks32_fwd": [P, P, I, I, P],
     "tup_blocks_stream_fwd": [P, P, I, I, P],
+    "tup_clock_probe": [P, P],
     "tup_pack_gather": [P, P, I, P, P, c_longlong, I, P],
     "tup_adam_step": [P, P, I, P],
     "tup_l1_loss_partial": [P, P, P, c_longlong, I, P],

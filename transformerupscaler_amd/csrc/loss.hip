@@ -66,3 +66,19 @@ extern "C" int tup_l1_loss_bwd(const float* a, const float* b, const float* gout
     TUP_CHECK_LAUNCH();
     return 0;
 }
+
+// Measurement aid of bench.py (`sustained.clock_GHz`): out[0] = s_memtime (shader cycles), out[1] = s_memrealtime (100 MHz) of one
+// wave, in stream order.  The shader clock a stretch of work ran at = (difference of two probes' out[0]) / (difference of their out[1])
+// x 100 MHz (MI355X_MICROARCH.md, 'DVFS give-back' item 6).  Not part of the model path.
+namespace {
+__global__ void clock_probe_kernel(unsigned long long* out)
+{
+    if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime(); out[1] = __builtin_amdgcn_s_memrealtime(); }
+}
+}  // namespace
+extern "C" int tup_clock_probe(void* out2, void* stream)
+{
+    clock_probe_kernel<<<dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream)>>>((unsigned long long*)out2);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}

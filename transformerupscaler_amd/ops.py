@@ -383,6 +383,13 @@ def fused_blocks32(x, table):
     return x
 
 
+def clock_probe():
+    """Two device int64 [2]: (shader cycles, 100 MHz ticks) of the stream position of the call; see bench.py `sustained`."""
+    out = torch.zeros(2, dtype=torch.int64, device=torch.device("cuda", _cur_dev()))
+    _lib.call("tup_clock_probe", out.data_ptr(), _stream())
+    return out
+
+
 def stream_table(blocks):
     """Pointer table for tup_blocks_stream_fwd: per block the 7 tensors of packing.pack_stream_block (wqk, wv, wproj, w1, w2, tab,
     sbias), validated here.  Returns (ctypes array, nblk, the tensors -- kept alive by the caller holding the tuple)."""

@@ -118,7 +118,11 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
     cap = capture
     x = x.contiguous().float()
     B, _, H, W = x.shape
-    feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
+    # (measured and dropped in round 4: conv1 -> conv2 and decoder_conv1 -> decoder_conv2 one or two images at a time, so that the
+    # 118 MB-per-image map between them would come back from the 256 MB memory-side cache: 0.693 -> 0.74-0.80 ms and 0.675 ->
+    # 0.70-0.72 ms per forward -- the consumers are not faster on cache-resident input, and eight small launches cost their tails)
+    with _stage("conv1"):
+        feat1 = ops.conv1(x, pk["conv1.w"], pk["conv1.b"], relu=True)
     with _stage("conv2"):
         feat = ops.conv_c64(feat1, pk["conv2.w"], pk["conv2.b"], 1, relu=True)
     del feat1
@@ -142,14 +146,18 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
         cap["feat"] = feat; cap["upscaled_input"] = upscaled_input
     del up
     # branch B: tokens
-    xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])
+    with _stage("patch_embed"):
+        xw = ops.patch_embed(feat, pk["pe.w"], pk["pe.b"])
     if cap is not None:
         cap["win_in"] = xw.clone()
     with _stage("blocks"):
         xw = transformer_blocks(pk, xw, bias_frags, cap)
-    combined = ops.patch_unembed(xw, pk["pu.w"], pk["pu.b"], feat)
-    dec = ops.conv_c64(combined, pk["dec1.w"], pk["dec1.b"], 1, relu=True)
-    residual = ops.conv_c64_thin(dec, pk["dec2.w"], pk["dec2.b"], 3, relu=False)
+    with _stage("unembed"):
+        combined = ops.patch_unembed(xw, pk["pu.w"], pk["pu.b"], feat)
+    with _stage("dec1"):
+        dec = ops.conv_c64(combined, pk["dec1.w"], pk["dec1.b"], 1, relu=True)
+    with _stage("dec2"):
+        residual = ops.conv_c64_thin(dec, pk["dec2.w"], pk["dec2.b"], 3, relu=False)
     if cap is not None:
         cap["combined"] = combined; cap["dec"] = dec; cap["residual"] = residual
     t = residual

@@ -91,25 +91,31 @@ def conv1(x, wp, bias, relu=True, in_mask=None, out_mask=None):
     return out
 
 
-def conv_c64(x, wp, bias, r=1, relu=False, add=None, mask=None, in_r=1):
+def conv_c64(x, wp, bias, r=1, relu=False, add=None, mask=None, in_r=1, out=None):
     """NHWC bf16 conv 64*in_r^2 -> 64*r*r with fused PixelShuffle(r); returns [B][H*r][W*r][64] bf16.
     x is [B][H*in_r][W*in_r][64] (in_r > 1: channels read through PixelShuffle^-1)."""
     B, Hi, Wi, C = x.shape
     assert C == 64 and Hi % in_r == 0 and Wi % in_r == 0
     H, W = Hi // in_r, Wi // in_r
     nt = r * r
-    out = torch.empty((B, H * r, W * r, 64), dtype=BF16, device=x.device)
+    if out is None:
+        out = torch.empty((B, H * r, W * r, 64), dtype=BF16, device=x.device)
+    else:
+        _chk(out, BF16, (B, H * r, W * r, 64), "out")
     _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (nt, in_r * in_r, 9, 64, 64), "wp"),
               _opt(bias, F32, (nt, 64), "bias"), _opt(add, BF16, out.shape, "add"), _opt(mask, BF16, out.shape, "mask"),
               out.data_ptr(), B, H, W, nt, r, 64, int(relu), 0, in_r, _stream())
     return out
 
 
-def conv_c64_thin(x, wp, bias, cout, relu=False):
+def conv_c64_thin(x, wp, bias, cout, relu=False, out=None):
     """NHWC bf16 conv 64 -> cout (<=16); returns fp32 planar [B][cout][H][W]."""
     B, H, W, C = x.shape
     assert C == 64 and 1 <= cout <= 16
-    out = torch.empty((B, cout, H, W), dtype=F32, device=x.device)
+    if out is None:
+        out = torch.empty((B, cout, H, W), dtype=F32, device=x.device)
+    else:
+        _chk(out, F32, (B, cout, H, W), "out")
     _lib.call("tup_conv3x3_c64_fwd", _chk(x, BF16, None, "x"), _chk(wp, BF16, (1, 1, 9, 16, 64), "wp"),
               _opt(bias, F32, (cout,), "bias"), None, None, out.data_ptr(), B, H, W, 1, 1, cout, int(relu), 1, 1, _stream())
     return out

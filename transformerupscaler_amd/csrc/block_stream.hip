@@ -707,7 +707,9 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
                 if constexpr (GE && n > 0) gelu_pins<(GELU_OPS * (n - 1)) / NM, (GELU_OPS * n) / NM>(gs, hfr[1 - PAR]);
 #endif
                 if constexpr (n + LA < NM) wq[(n + LA) % RS] = frag(std::integral_constant<int, n + LA>{});
-                if constexpr (n + 1 < NM) lds_wait<(NM - 2 - n < LA - 1 ? NM - 2 - n : LA - 1)>();
+                // (one wait per TWO gaps: at even n the fragments of MFMAs n + 1 and n + 2 are made ready -- every instruction of a gap is an
+                // issue slot of the SIMD)
+                if constexpr ((n & 1) == 0 && n + 1 < NM) lds_wait<(NM - 3 - n < LA - 2 ? (NM - 3 - n < 0 ? 0 : NM - 3 - n) : LA - 2)>();
 #ifndef TUP_BSX_NOGELU        // timing experiment (wrong results): ... without the GELU arithmetic (fc1's accumulators kept alive)
                 if constexpr (GE) gelu_ops<(GELU_OPS * n) / NM, (GELU_OPS * (n + 1)) / NM>(gs, acc1[1 - PAR], hfr[1 - PAR]);
 #else

@@ -231,6 +231,7 @@ def main():
                     help="both = headline inference + 4x 540p inference (config 4) + FastTransformer training step + "
                          "ResidualTransformer 6x training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the 2-second sustained loop (profiling runs)")
     args = ap.parse_args()
 
     if launcher_decision(args.gpus, os.environ) == "spawn":          # before any GPU call in this process
@@ -532,7 +533,7 @@ def main():
     # which the chip still holds its boost clock).  The shader clock of the stretch = shader cycles / 100 MHz ticks between two one-wave
     # probes in stream order (MI355X_MICROARCH.md, 'DVFS give-back' item 6).
     sustained = None
-    if rank == 0:
+    if rank == 0 and not args.no_sustained:
         from transformerupscaler_amd import ops as _ops
         with torch.no_grad():
             torch.cuda.synchronize()

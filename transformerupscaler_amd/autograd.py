@@ -43,7 +43,7 @@ def site_seed(seed: int, block: int, site: int) -> int:
     return (seed * 0x9E3779B9 + (3 * block + site + 1) * 0x85EBCA6B) & 0xFFFFFFFF
 
 
-pe_merge = not os.environ.get("TUP_NO_PE_MERGE")          # A/B switch: the gradient merge at `feat` inside patch_embed's input gradient
+pe_merge = True          # A/B attribute (tests flip it): the gradient merge at `feat` inside patch_embed's input gradient
 
 
 def forward_train(pk, frags_t, x, scale, res_out, require_ratio, drop_p=0.0, seed=0):

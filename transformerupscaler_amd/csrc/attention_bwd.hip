@@ -381,7 +381,7 @@ namespace {
 // is one workgroup per CU, every workgroup the same number of sweeps.  TUP_LN_BWD_BLOCKS overrides (timing experiments).
 int ln_bwd_blocks(int M)
 {
-    static const int cap = [] { const char* e = getenv("TUP_LN_BWD_BLOCKS"); return e ? atoi(e) : 256; }();
+    static const int cap = TUP_ENV_INT("TUP_LN_BWD_BLOCKS", 256);
     const int groups = (M + 15) / 16;
     const int sweeps = (groups + cap - 1) / cap;
     return (groups + sweeps - 1) / sweeps;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict_
 // idle in the second: 186 -> 154 us.  TUP_ATTN_BWD_SLOTS overrides (timing experiments).
 inline int attn_bwd_slots(int nwin, int heads)
 {
-    static const int forced = [] { const char* e = getenv("TUP_ATTN_BWD_SLOTS"); return e ? atoi(e) : 0; }();
+    static const int forced = TUP_ENV_INT("TUP_ATTN_BWD_SLOTS", 0);
     const int cap = forced > 0 ? forced : 1024 / heads;
     return nwin < cap ? nwin : cap;
 }

@@ -236,22 +236,15 @@ TUP_DEVICE unsigned long long bs_now() {
 }
 
 template <bool STAMPS>
-__global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restrict__ xio, int nwin, const StreamTable tbl, int nblk,
-                                                                 int first_round, int stagger)
+__global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restrict__ xio, int nwin, const StreamTable tbl, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = lds_addr(smem);
     f32x16 R[6];
     bf16x8 tf[12];
     LnStats ln1{};       // LayerNorm1's sums over tiles 0-3 of the NEXT block's input ride in the gaps of the last MLP slot
-    // Every workgroup runs the same program from the same start, so without this the whole chip stores its residual stream (and
-    // re-reads it) in the same few microseconds of every block: 47 MB per burst at the HBM write rate = 30 k cycles per block in the
-    // stamps.  The workgroups of the first round (one per CU) start `stagger` cycles apart in eight phases; the second round inherits
-    // the phases (a CU takes its next workgroup when it is done), and the last phase's CUs are the ones that get no second workgroup.
-    if (stagger > 0 && (int)blockIdx.x < first_round) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), d = (unsigned long long)(blockIdx.x & 7) * (unsigned)stagger;
-        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(64);
-    }
+    // (Measured and removed: a start stagger of the first round's workgroups in eight phases, against the chip-wide bursts of the
+    // parking stores: 849.0 vs 850.4 us -- the parking is bound by each CU's own issue rate)
     unsigned long long ph[BS_NPH] = {}, tprev = 0, tstart = 0;
     if constexpr (STAMPS) tprev = tstart = bs_now();
 #define BS_STAMP(K) do { if constexpr (STAMPS) { const unsigned long long t_ = bs_now(); ph[K] += t_ - tprev; tprev = t_; } } while (0)
@@ -795,22 +788,17 @@ extern "C" int tup_blocks_stream_fwd(float* x, const void* const* table, int nbl
         t.b[i] = StreamBlock{(const char*)r[0], (const char*)r[1], (const char*)r[2], (const char*)r[3], (const char*)r[4],
                              (const float*)r[5], (const float*)r[6]};
     }
-    // start stagger (see the kernel): cycles between two of the eight phases; TUP_BS_STAGGER overrides (0 = off)
-    static const int stagger_env = [] { const char* e = getenv("TUP_BS_STAGGER"); return e ? atoi(e) : -1; }();
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
     const int nwg = (nwin + 3) / 4;
-    const int stagger = stagger_env > 0 ? stagger_env : 0;        // measured: no effect (849.0 vs 850.4 us); off
 #ifdef TUP_DIAG
     if (getenv("TUP_BS_STAMPS")) {
         TUP_SET_DYN_LDS(blocks_stream_kernel<true>, BS_LDS);
-        blocks_stream_kernel<true><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, nwin, t, nblk, cus, stagger);
+        blocks_stream_kernel<true><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, nwin, t, nblk);
         TUP_CHECK_LAUNCH();
         return 0;
     }
 #endif
     TUP_SET_DYN_LDS(blocks_stream_kernel<false>, BS_LDS);
-    blocks_stream_kernel<false><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, nwin, t, nblk, cus, stagger);
+    blocks_stream_kernel<false><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, nwin, t, nblk);
     TUP_CHECK_LAUNCH();
     return 0;
 }

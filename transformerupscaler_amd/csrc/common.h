@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -289,5 +290,15 @@ inline void drop_pair_params(float p, uint32_t& thresh_hi, float& inv_keep) {
             e_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
             if (e_ != hipSuccess) return (int)e_; \
             done_ |= 1ull << (dev_ & 63); } } while (0)
+
+// A/B switches, tuning knobs and timing ablations are read from the environment ONLY in the diagnostic library (`make diag`,
+// -DTUP_DIAG); the product library compiles the defaults in and reads no TUP_* variable.
+#ifdef TUP_DIAG
+#define TUP_ENV_FLAG(name) (getenv(name) != nullptr)
+#define TUP_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define TUP_ENV_FLAG(name) false
+#define TUP_ENV_INT(name, dflt) (dflt)
+#endif
 
 #define TUP_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

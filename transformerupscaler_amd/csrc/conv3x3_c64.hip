@@ -866,7 +866,7 @@ int launch_bra_rows(const void* x, const void* wp, const float* bias, float* out
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const int grid = (int)(nt < 256 ? nt : 256);                 // one workgroup per CU
-    static const int ablate = getenv("TUP_BRA_ABLATE") ? atoi(getenv("TUP_BRA_ABLATE")) : 0;     // timing experiments: 1 no K loop, 2 no stores, 4 no DMA
+    static const int ablate = TUP_ENV_INT("TUP_BRA_ABLATE", 0);     // timing experiments: 1 no K loop, 2 no stores, 4 no DMA
     bra_rows_persistent_kernel<<<dim3(grid), dim3(512), lds, s>>>((const bf16_t*)x, (const bf16_t*)wp, bias, out, B, H, W, relu, tilesX, tilesY, ablate);
     TUP_CHECK_LAUNCH();
     return 0;
@@ -1104,7 +1104,7 @@ extern "C" int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* b
     const long long nblk = (long long)tilesX * tilesY * B;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const bool use_persistent = (getenv("TUP_CONV_NONPERSISTENT") == nullptr);
+    static const bool use_persistent = !TUP_ENV_FLAG("TUP_CONV_NONPERSISTENT");
     if (in_r == 1 && use_persistent) {
         if (out_mode == OUT_NHWC_BF16) {
             if (ntiles != r * r || r < 1) return (int)hipErrorInvalidValue;
@@ -1112,7 +1112,7 @@ extern "C" int tup_conv3x3_c64_fwd(const void* x, const void* wp, const float* b
         }
         if (out_mode == OUT_PLANAR_F32) {
             if (ntiles != 1 || r != 1 || cout_valid < 1 || cout_valid > 16 || add || mask) return (int)hipErrorInvalidValue;
-            static const bool thin_pingpong = (getenv("TUP_THIN_PINGPONG") != nullptr);      // A/B: the round 1-2 form
+            static const bool thin_pingpong = TUP_ENV_FLAG("TUP_THIN_PINGPONG");      // A/B: the round 1-2 form
             if (cout_valid <= 4 && !thin_pingpong) return launch_thin_rows(x, wp, bias, (float*)out, B, H, W, cout_valid, relu, s);
             return launch_persistent<1, OUT_PLANAR_F32, 3>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, 1, cout_valid, relu, s);
         }
@@ -1159,8 +1159,8 @@ extern "C" int tup_conv5x5_c64_planar_fwd(const void* x, const void* wp, const f
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nout = 3 * r * r;
-    static const bool use_persistent5 = (getenv("TUP_CONV_NONPERSISTENT") == nullptr);
-    static const bool use_taps25 = (getenv("TUP_BRA_TAPS25") != nullptr);       // A/B: the 25-tap form of round 1-2
+    static const bool use_persistent5 = !TUP_ENV_FLAG("TUP_CONV_NONPERSISTENT");
+    static const bool use_taps25 = TUP_ENV_FLAG("TUP_BRA_TAPS25");       // A/B: the 25-tap form of round 1-2
     if (r == 2 && use_persistent5) {
         int e = use_taps25 ? launch_persistent<1, OUT_PLANAR_F32, 5>(x, wp, bias, nullptr, nullptr, out, B, H, W, 1, r, nout, relu, s)
                            : launch_bra_rows(x, wp, bias, out, B, H, W, relu, s);

@@ -915,7 +915,7 @@ extern "C" int tup_conv3x3_planar_dgrad(const float* gpl, const float* w, float*
 {
     if (B <= 0) return 0;
     if (r < 1 || r > 6 || B > 65535) return (int)hipErrorInvalidValue;
-    static const bool one_px = getenv("TUP_PLANAR_ONE_PIXEL") != nullptr;           // A/B switch
+    static const bool one_px = TUP_ENV_FLAG("TUP_PLANAR_ONE_PIXEL");           // A/B switch
     if (r == 2 && W % 4 == 0 && !one_px) {
         conv3x3_dgrad_planar_r2x4_kernel<<<dim3((W / 4 + 63) / 64, (H + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(gpl, w, gx, H, W);
         TUP_CHECK_LAUNCH();
@@ -938,7 +938,7 @@ extern "C" int tup_resize_aa_bwd(const float* gout, const float* pre, float* gin
     if (planes > 65535 || (l1_scale && !pre)) return (int)hipErrorInvalidValue;
     // separable kernel when a column is referenced by <= 6 outputs (an output reads KX adjacent columns, so an input column feeds at
     // most KX * Wo / Wi + 2 outputs) and RB_TR input rows never reference more than RB_MAXR output rows
-    static const bool gather = getenv("TUP_RESIZE_GATHER") != nullptr;             // A/B switch
+    static const bool gather = TUP_ENV_FLAG("TUP_RESIZE_GATHER");             // A/B switch
     if (!gather && (long long)KX * Wo / Wi + 2 <= 6 && (long long)RB_TR * Ho / Hi + KY + 2 <= RB_MAXR) {
         resize_aa_bwd_sep_kernel<<<dim3((Wi + 255) / 256, (Hi + RB_TR - 1) / RB_TR, planes), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
             gout, pre, gin, ymin, yw, KY, xmin, xw, KX, oy0, oyn, ox0, oxn, Hi, Wi, Ho, Wo, l1_scale);

@@ -511,13 +511,13 @@ extern "C" int tup_conv3x3_c3_fwd(const float* x, const void* wp, const float* b
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nblk = (long long)tilesX * tilesY * B;
     if (nblk > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    static const bool one_tile = getenv("TUP_CONV1_ONE_TILE") != nullptr;      // A/B switch: the non-persistent kernel
+    static const bool one_tile = TUP_ENV_FLAG("TUP_CONV1_ONE_TILE");      // A/B switch: the non-persistent kernel
     if (!one_tile && (long long)B * 3 * H * W < (1LL << 31)) {
         // three workgroups are resident per CU (140 registers): grids of 3, 6 or 12 per CU run the same 282-285 us at 8 x 720p, 2 or 4
         // per CU (a partial round) 330 us
-        static const int per_cu = [] { const char* e = getenv("TUP_CONV1_WG_PER_CU"); return e ? atoi(e) : 2 * TUP_CONV1_OCC; }();
+        static const int per_cu = TUP_ENV_INT("TUP_CONV1_WG_PER_CU", 2 * TUP_CONV1_OCC);
         const unsigned grid = (unsigned)(nblk < 256 * per_cu ? nblk : 256 * per_cu);
-        static const int xcd_bands = getenv("TUP_CONV1_NO_XCD_BANDS") ? 0 : 1;
+        static const int xcd_bands = TUP_ENV_FLAG("TUP_CONV1_NO_XCD_BANDS") ? 0 : 1;
         conv3x3_c3_persistent_kernel<<<dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
             x, (const bf16_t*)wp, bias, in_mask, (const bf16_t*)out_mask, (bf16_t*)out, H, W, relu, tilesX, tilesY, (int)nblk, xcd_bands);
         TUP_CHECK_LAUNCH();
@@ -535,7 +535,7 @@ extern "C" int tup_conv3x3_planar_fwd(const float* x, const float* w28, const fl
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     if (r < 1 || r > 6 || B > 65535) return (int)hipErrorInvalidValue;
     const int cout = 3 * r * r;
-    static const bool one_px = getenv("TUP_PLANAR_ONE_PIXEL") != nullptr;           // A/B switch
+    static const bool one_px = TUP_ENV_FLAG("TUP_PLANAR_ONE_PIXEL");           // A/B switch
     if (r == 1 && W % 4 == 0 && !one_px) {
         conv3x3_planar_r1x4_kernel<<<dim3((W / 4 + 63) / 64, (H + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
             x, w28, bias, add, out, H, W, clamp01);
@@ -557,7 +557,7 @@ extern "C" int tup_resize_aa_fwd(const float* in, float* out, const int* ymin, c
     if (planes > 65535) return (int)hipErrorInvalidValue;
     // separable kernel when every column has <= 8 taps and RS_TR output rows never span more than RS_MAXR input rows
     // (RS_TR / ratio + KY + 1 is an upper bound of the span)
-    static const bool gather = getenv("TUP_RESIZE_GATHER") != nullptr;             // A/B switch
+    static const bool gather = TUP_ENV_FLAG("TUP_RESIZE_GATHER");             // A/B switch
     if (!gather && KX <= 8 && (long long)RS_TR * Hi / Ho + KY + 2 <= RS_MAXR) {
         resize_aa_sep_kernel<<<dim3((Wo + 255) / 256, (Ho + RS_TR - 1) / RS_TR, planes), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
             in, out, ymin, ysize, yw, KY, xmin, xsize, xw, KX, Hi, Wi, Ho, Wo, clamp01, (size_t)planes * Ho * Wo);

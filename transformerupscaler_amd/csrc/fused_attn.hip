@@ -754,7 +754,7 @@ int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* str
     // launches of at most 512 windows (the chip's workgroup slots: 256 CUs x 2) run ONE window per workgroup, 16 token rows per wave:
     // twice the workgroups, half the serial work per wave -- the 720p -> 4K overlay frame (240 windows) 1.237 -> 1.166 ms; config 4's
     // 540 windows would be 1.05 rounds that way (2.59 vs 2.56 ms) and stay on the two-window form.  TUP_BLOCK_ONE_WINDOW=0 / 1 forces a form.
-    static const int force1 = [] { const char* e = getenv("TUP_BLOCK_ONE_WINDOW"); return e ? atoi(e) : -1; }();
+    static const int force1 = TUP_ENV_INT("TUP_BLOCK_ONE_WINDOW", -1);
     const bool one_window = force1 >= 0 ? force1 != 0 : nwin <= 512;
     const dim3 grid((nwin + 1) / 2);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -768,10 +768,10 @@ int launch_blocks32(float* x, const BlockTable& t, int nblk, int nwin, void* str
 #endif
     } else {
         TUP_SET_DYN_LDS((fused_qkv_attn_kernel<true, true>), FB_LDS);
-        // wave priority of every second resident set (see the kernel's first lines); TUP_BLOCK_PRIO=0 switches it off
+        // wave priority of every second resident set (see the kernel's first lines); diagnostic library: TUP_BLOCK_PRIO=0 switches it off
         static const int prio = [] {
-            const char* e = getenv("TUP_BLOCK_PRIO");
-            if (e) return atoi(e);
+            const int forced = TUP_ENV_INT("TUP_BLOCK_PRIO", -1);
+            if (forced >= 0) return forced;
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
             if (cus <= 0 || (cus & (cus - 1))) return 0;         // the bit test needs a power of two (MI355X: 256)

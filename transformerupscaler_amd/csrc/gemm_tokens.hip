@@ -900,7 +900,7 @@ int launch_panel(const GemmParams& p, hipStream_t s)
 {
     if (p.M <= 0) return 0;
     if (p.N % 64 != 0 || p.K != PK) return (int)hipErrorInvalidValue;
-    static const bool use_v1 = (getenv("TUP_GEMM_PANEL_V1") != nullptr);
+    static const bool use_v1 = TUP_ENV_FLAG("TUP_GEMM_PANEL_V1");
     if (!use_v1) {
         gemm_panel2_kernel<AMODE, EPI><<<dim3((p.M + PBM - 1) / PBM), dim3(256), 2 * PW_BYTES, s>>>(p);
         TUP_CHECK_LAUNCH();
@@ -1086,7 +1086,7 @@ int launch_patch_embed(const GemmParams& p, hipStream_t s)
 
 int launch_patch_embed_any(const GemmParams& p, hipStream_t s)
 {
-    static const bool use_old = (getenv("TUP_PATCH_EMBED_V1") != nullptr);
+    static const bool use_old = TUP_ENV_FLAG("TUP_PATCH_EMBED_V1");
     // the kernel keeps 32-bit byte offsets into the map: fine up to 4 GB of NHWC bf16 (B*H*W < 33.5 M pixels)
     const long long per_img = p.linear_tokens ? (long long)p.Ht * p.Wt_ : (long long)p.nWy * p.nWx * 64;
     const long long nimg = per_img > 0 ? p.M / per_img : 0;
@@ -1123,7 +1123,7 @@ extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const vo
     if ((epilogue == 1 || epilogue == 2) && !bias) return (int)hipErrorInvalidValue;
     if (epilogue == 2 && !res) return (int)hipErrorInvalidValue;
     if (epilogue == 3 && !aux) return (int)hipErrorInvalidValue;
-    static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
+    static const bool use_panel = !TUP_ENV_FLAG("TUP_GEMM_NOPANEL");
     if (K == PK && use_panel) {
         if (a_dtype == 0) {
             if (epilogue == 0) return launch_panel<A_BF16, E_BF16>(p, s);
@@ -1136,7 +1136,7 @@ extern "C" int tup_gemm_tokens_fwd(const void* A, int a_dtype, int lda, const vo
         }
         return (int)hipErrorInvalidValue;
     }
-    static const bool use_big = (getenv("TUP_GEMM_NOBIG") == nullptr);
+    static const bool use_big = !TUP_ENV_FLAG("TUP_GEMM_NOBIG");
     if (use_big && a_dtype == 0 && N == 192 && K > PK && K % 64 == 0 && M >= 4096) {       // long-K Linear layers onto the big tile
         if (epilogue == 0) return launch_patch_embed<3, A_BF16, E_BF16>(p, s);
         if (epilogue == 2) return launch_patch_embed<3, A_BF16, E_RES_F32>(p, s);
@@ -1178,7 +1178,7 @@ extern "C" int tup_patch_unembed_fwd(const float* x, const void* Wt, const float
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = x; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
-    static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
+    static const bool use_panel = !TUP_ENV_FLAG("TUP_GEMM_NOPANEL");
     if (use_panel) return launch_panel<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }
@@ -1218,7 +1218,7 @@ extern "C" int tup_patch_embed_bwd(const float* gx, const void* Wt, void* gmap_p
     p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8;
     p.A = gx; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = nullptr; p.out = gmap_pad; p.skip = nullptr;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
-    static const bool use_panel = (getenv("TUP_GEMM_NOPANEL") == nullptr);
+    static const bool use_panel = !TUP_ENV_FLAG("TUP_GEMM_NOPANEL");
     if (use_panel) return launch_panel<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -284,7 +284,7 @@ int launch(WgradParams p, hipStream_t s)
     if (msplit < 1) msplit = 1;
     p.mchunk = (((p.M + msplit - 1) / msplit) + 63) / 64 * 64;
     msplit = (p.M + p.mchunk - 1) / p.mchunk;
-    static const int remap = getenv("TUP_WGRAD_NO_XCD") ? 0 : 1;            // A/B switch
+    static const int remap = TUP_ENV_FLAG("TUP_WGRAD_NO_XCD") ? 0 : 1;            // A/B switch
     p.xcd_remap = remap;
     gemm_wgrad_kernel<PMODE, QMODE><<<dim3(p.NI / 64, p.NJ / 64, msplit), dim3(256), 0, s>>>(p);
     TUP_CHECK_LAUNCH();
@@ -366,7 +366,7 @@ extern "C" int tup_colsum(const void* G, int dtype, int ld, float* out, int M, i
     if (N % 64 != 0 || ld % 8 != 0) return (int)hipErrorInvalidValue;
     // every workgroup ends with 64 float atomics on the same addresses (they serialise in L2): a few hundred workgroups, not thousands
     // (the 64-column map sums: 2,048 workgroups 106 us, 512 95 us; three column stripes of token rows are flat from 512 to 2,048)
-    static const int forced = [] { const char* e = getenv("TUP_COLSUM_BLOCKS"); return e ? atoi(e) : 0; }();
+    static const int forced = TUP_ENV_INT("TUP_COLSUM_BLOCKS", 0);
     const int target = forced > 0 ? forced : (N == 64 ? 512 : 2048);
     int msplit = target / (N / 64);
     if (msplit < 1) msplit = 1;

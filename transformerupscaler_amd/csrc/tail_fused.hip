@@ -321,17 +321,17 @@ extern "C" int tup_tail_fused_fwd(const float* x, const float* wfu, const float*
     p.ymin = ymin; p.ysize = ysize; p.yw = yw; p.KY = KY; p.xmin = xmin; p.xsize = xsize; p.xw = xw; p.KX = KX;
     EW = (EW + 1) & ~1;                   // even row pitches (see the kernel's LDS layout)
     p.H = H; p.W = W; p.r = r; p.Ho = Ho; p.Wo = Wo; p.EH = EH; p.EW = EW; p.clamp01 = clamp01;
-    static const int stamps_on = getenv("TUP_TAIL_STAMPS") ? 1 : 0;
+    static const int stamps_on = TUP_ENV_FLAG("TUP_TAIL_STAMPS") ? 1 : 0;
     p.stamps = stamps_on;
-    static const int abl = getenv("TUP_TAIL_ABLATE") ? atoi(getenv("TUP_TAIL_ABLATE")) : 0;      // timing experiments only (results are wrong)
+    static const int abl = TUP_ENV_INT("TUP_TAIL_ABLATE", 0);      // timing experiments only (results are wrong)
     p.abl = abl;
     p.LH = (EH + 2) / r + 4; p.LW = ((EW + 2) / r + 4 + 1) & ~1;
     const int nfu = 3 * r * r;
     const size_t lds = ((size_t)nfu * 28 + ((nfu + 1) & ~1) + 88 + 3 * (size_t)p.LH * p.LW + 3 * (size_t)(EH + 2) * (EW + 2) + 3 * (size_t)EH * EW + 2) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     // OCC = waves per SIMD the register allocator must allow: 4 (<= 128 VGPRs, 16 waves per CU) or 2
-    static const bool occ2 = getenv("TUP_TAIL_OCC2") != nullptr;
-    static const bool occ3 = getenv("TUP_TAIL_OCC3") != nullptr;        // 170 VGPRs: no spills, three workgroups per CU
+    static const bool occ2 = TUP_ENV_FLAG("TUP_TAIL_OCC2");
+    static const bool occ3 = TUP_ENV_FLAG("TUP_TAIL_OCC3");        // 170 VGPRs: no spills, three workgroups per CU
     dim3 grid((Wo + OT_W - 1) / OT_W, (Ho + OT_H - 1) / OT_H, B);
 #define TUP_TAIL_LAUNCH(OCC, ST) do { \
         hipError_t e = hipFuncSetAttribute((const void*)tail_fused_kernel<OCC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

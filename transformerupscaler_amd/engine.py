@@ -21,7 +21,7 @@ from .weights import BLOCKS, VALID_SCALES, upsampler_layout
 stage_timer = None
 # inference fusion level of the attention half: 2 = norm1 + qkv + attention + proj + residual in one kernel,
 # 1 = norm1 + qkv + attention (proj separate), 0 = separate kernels
-fuse_attention = 0 if os.environ.get("TUP_NO_FUSED_ATTN") else int(os.environ.get("TUP_FUSED_ATTN_LEVEL", "3"))
+fuse_attention = 3      # A/B attribute (tests set 0 .. 3; no environment switch)
 
 
 class _NullCtx:
@@ -47,15 +47,15 @@ def resolve_scale(h: int, w: int, res_out, upscale_factor: Optional[int]):
     return (int(res_out[0]), int(res_out[1])), int(upscale_factor)
 
 
-blocks_in_one_launch = not os.environ.get("TUP_BLOCKS_SEPARATE_LAUNCHES")     # inference: the six whole-block kernels as one launch
-# inference: the one launch is the streamed 32x32x16 kernel (csrc/block_stream.hip); TUP_BLOCKS_16X16=1 = round 3's 16x16x32 kernel (A/B)
-stream_blocks = not os.environ.get("TUP_BLOCKS_16X16")
+blocks_in_one_launch = True     # inference (A/B attribute): the six whole-block kernels as one launch
+# inference: the one launch is the streamed 32x32x16 kernel (csrc/block_stream.hip); False = round 3's 16x16x32 kernel (A/B attribute)
+stream_blocks = True
 # the streamed kernel's workgroup carries four windows (one workgroup per CU): launches that would leave most CUs without one stay on the
 # 16x16x32 kernel, whose small-launch form runs one window per workgroup (the 720p -> 4K overlay frame: 240 windows; config 4: 540)
-STREAM_MIN_WINDOWS = int(os.environ.get("TUP_STREAM_MIN_WINDOWS", "512"))
+STREAM_MIN_WINDOWS = 512
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
-stream_tail = not os.environ.get("TUP_NO_STREAM_TAIL")     # last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
+stream_tail = True     # A/B attribute; last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
 
 
 def _block_operands(pk, i, bias_frags):

@@ -20,8 +20,8 @@ from .weights import VALID_SCALES, upsampler_layout
 
 
 # training: run the last x2 Upsampler stage + up1_conv (and their backward) through the exact composition; False = explicit kernels
-compose_branch_a_in_training = not os.environ.get("TUP_NO_COMPOSED_TRAIN")
-use_pack_plan = not os.environ.get("TUP_NO_PACK_PLAN")          # training re-pack as two gather launches (pack_plan.py)
+compose_branch_a_in_training = True          # A/B attribute
+use_pack_plan = True          # A/B attribute: training re-pack as two gather launches (pack_plan.py)
 
 
 class _ConvParams(nn.Module):

@@ -11,11 +11,13 @@ import torch.nn.functional as F
 
 from .autograd import l1_loss, resize_aa
 
+use_torch_adam = False          # A/B attribute
+
 
 def make_optimizer(model, lr: float = 1e-4):
     """train.py:104 -- Adam, default betas/eps, no weight decay (parameters without grad are skipped).  `optim.Adam` is
-    torch.optim.Adam with the whole update in one HIP launch; TUP_TORCH_ADAM=1 selects torch's own step."""
-    if os.environ.get("TUP_TORCH_ADAM"):
+    torch.optim.Adam with the whole update in one HIP launch; harness.use_torch_adam = True selects torch's own step (A/B)."""
+    if use_torch_adam:
         return torch.optim.Adam(model.parameters(), lr=lr)
     from .optim import Adam
     return Adam(model.parameters(), lr=lr)

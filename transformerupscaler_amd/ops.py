@@ -54,7 +54,7 @@ def _opt(t, dtype, shape, name):
 # bias gradients).  One torch.zeros of the whole lot + views replaces 130 fill launches.  The pool is a fresh allocation per
 # backward pass and stays alive as long as any gradient view does, so there is no reuse hazard. ----
 _zero_pool = None          # [tensor, next free offset (floats)]
-_ZERO_POOL_FLOATS = int(os.environ.get("TUP_ZERO_POOL_FLOATS", str(9 * 1024 * 1024)))
+_ZERO_POOL_FLOATS = 9 * 1024 * 1024
 
 
 def zero_pool_begin(device):
@@ -847,7 +847,7 @@ def _bicubic_t_on(device, in_size, out_size):
 
 _BICB_CACHE = {}
 _BIC_YB = 16
-bicubic_bwd_banded = not os.environ.get("TUP_BICUBIC_BWD_GATHER")        # A/B switch: per-source-row gather of the row pass
+bicubic_bwd_banded = True        # A/B attribute: per-source-row gather of the row pass
 
 
 def _bicubic_bands_on(device, in_size, out_size):

@@ -19,6 +19,8 @@ import torch.nn as nn
 from . import ops, packing
 from .fast_transformer import _ConvParams, _LayerNormParams, _LinearParams
 
+use_pack_plan = True          # A/B attribute: training re-pack as two gather launches (pack_plan.py)
+
 
 class _MHAParams(nn.Module):
     """Parameter layout of nn.MultiheadAttention(embed, heads): in_proj_weight/bias + out_proj.{weight,bias}."""
@@ -81,7 +83,7 @@ class TransformerModel(nn.Module):
         hit = self._pack_cache.get(bool(backward))
         if hit is None or hit[0] != ver:
             sd, pk = dict(self.named_parameters()), None
-            if backward and not os.environ.get("TUP_NO_PACK_PLAN"):       # training: re-pack = two gather launches (pack_plan.py)
+            if backward and use_pack_plan:       # training: re-pack = two gather launches (pack_plan.py)
                 from .pack_plan import packed_with_plan
                 pk = packed_with_plan(self, "rt", sd, lambda d: packing.pack_rt_state_dict(d, backward=True))
             hit = (ver, pk if pk is not None else packing.pack_rt_state_dict(sd, backward=backward))

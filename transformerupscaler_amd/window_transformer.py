@@ -20,6 +20,8 @@ import torch.nn as nn
 from . import ops, packing
 from .fast_transformer import WindowTransformerBlock, _ConvParams
 
+use_pack_plan = True          # A/B attribute: training re-pack as two gather launches (pack_plan.py)
+
 
 def pad_to_even(feat: torch.Tensor) -> torch.Tensor:
     """NHWC map with an odd height / width -> one zero row / column appended.  The stride-2, pad-1 conv of the reference
@@ -71,7 +73,7 @@ class TransformerModel(nn.Module):
         hit = self._pack_cache.get(bool(backward))
         if hit is None or hit[0] != ver:
             sd, pk = dict(self.named_parameters()), None
-            if backward and not os.environ.get("TUP_NO_PACK_PLAN"):       # training: re-pack = two gather launches (pack_plan.py)
+            if backward and use_pack_plan:       # training: re-pack = two gather launches (pack_plan.py)
                 from .pack_plan import packed_with_plan
                 pk = packed_with_plan(self, "wt", sd, lambda d: packing.pack_wt_state_dict(d, backward=True))
             if pk is None:

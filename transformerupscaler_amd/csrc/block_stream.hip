@@ -52,6 +52,12 @@ constexpr int T_QKB = 0, T_B1 = 384, T_BP = 1152, T_B2 = 1344;
 constexpr int PROJ_T[6] = {L_WV, L_WQK, L_WV + TILE, L_WQK + TILE, L_B, L_B + TILE};
 
 struct StreamBlock { const char* wqk; const char* wv; const char* wproj; const char* w1; const char* w2; const float* tab; const float* sbias; };
+// one slot of the MLP half: fc1 of chunk c (F1) | GELU of chunk c - 1 (GE) | fc2 of chunk c - 2 (F2); DM: the slot also requests weights
+template <int PAR_, bool F1_, bool GE_, bool F2_, bool DM_> struct MlpSlot {
+    static constexpr int PAR = PAR_, NM = (F1_ && F2_) ? 24 : 12;
+    static constexpr bool F1 = F1_, GE = GE_, F2 = F2_, DM = DM_;
+    static constexpr bool LNS = !F1_ && !GE_ && F2_;       // the last slot: tile t's accumulators are final behind MFMA 2 t + 1
+};
 constexpr int BS_MAX_BLK = 8;
 struct StreamTable { StreamBlock b[BS_MAX_BLK]; };
 
@@ -83,6 +89,22 @@ TUP_DEVICE __amdgpu_buffer_rsrc_t bs_rsrc(const void* p) { return __builtin_amdg
 TUP_DEVICE void bs_dma(__amdgpu_buffer_rsrc_t r, char* lds_dst, uint32_t lane16, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)lane16, soff, 0, 0);
 }
+
+// The same piece inside an MFMA stream: requested only by the waves whose LDS base has bit 31 clear, with the branch INSIDE the asm
+// statement -- a C++ `if` around the builtin splits the stream into basic blocks, across which hipcc moves the GELU arithmetic out of
+// its gaps unless every value is pinned (and every pin next to a packed instruction costs an s_nop) -- and with the piece's offset in
+// the instruction's immediate field, which moves the LDS address and the source address alike: one LDS base and one source offset
+// per group of up to four pieces instead of four scalar additions per piece.  (hipcc does not see the request: nothing but the
+// hand-counted barrier_all() waits for it.  The predicate rides in the LDS base because a separate scalar operand that lives
+// across the block loop came out of register allocation as a VGPR.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int OFF> TUP_DEVICE void bs_dma_on(__amdgpu_buffer_rsrc_t rs, uint32_t lds_base, uint32_t lane16, uint32_t soff) {
+    static_assert(OFF >= 0 && OFF < 4096, "12-bit immediate offset");
+    asm volatile("s_bitcmp1_b32 %0, 31\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds\n1:"
+                 :: "s"(lds_base), "v"(lane16), "s"(rs), "s"(soff), "n"(OFF) : "memory", "scc", "m0");
+}
+#pragma clang diagnostic pop
 
 TUP_DEVICE bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
     return __builtin_bit_cast(bf16x8, u32x4{pack_bf16x2(a0, a1), pack_bf16x2(a2, a3), pack_bf16x2(a4, a5), pack_bf16x2(a6, a7)});
@@ -177,34 +199,35 @@ template <int K0, int K1> TUP_DEVICE void softmax_ops(SmState& st, f32x16 (&S)[2
 // sched_barrier binds only the machine scheduler), so the four results of a step pass through ONE empty volatile asm behind the
 // step's last operation.  (One asm per result cost an s_nop each -- hipcc pads a packed instruction that follows an inline asm --
 // and an asm between the conversion and the clamp a canonicalising v_pk_max per value: 47 + 32 instructions per pair of slots.)
-constexpr int GELU_OPS = 80;
-struct GeluState { h2 x[4], xc[4], sv[4], q[4]; };
-#define TUP_PIN4(A) asm volatile("" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]))
+constexpr int GELU_OPS = 64;                  // = its instructions: 2 x (4 conversions + 7 steps x 4 packed pairs)
+struct GeluState { h2 x[4], sv[4], q[4]; };
+// One value of a step's four is pinned: with the slot one basic block that holds the whole step in its gap, and the pinned value's
+// consumer is the LAST operation of the next step -- three instructions away from the asm, so no hazard s_nop is owed.
+#define TUP_PIN4(A) asm volatile("" : "+v"(A[3]))
 template <int K> TUP_DEVICE void gelu_op(GeluState& g, const f32x16& acc, bf16x8 (&hf)[2]) {
-    constexpr int b = K / 40, k = K % 40;
-    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+    constexpr int b = K / 32, k = K % 32;
     if constexpr (k < 4) {
         g.x[k] = __builtin_convertvector(f32x2{acc[8 * b + 2 * k], acc[8 * b + 2 * k + 1]}, h2);
     } else {
         constexpr int t = (k - 4) >> 2, i = (k - 4) & 3;
-        constexpr float C[4] = {-1.28229402f, 0.86809017f, -0.66956203f, 0.70398137f};
-        if constexpr (t == 0) g.xc[i] = __builtin_elementwise_min(__builtin_elementwise_max(g.x[i], -one), one);
-        else if constexpr (t == 1) g.sv[i] = __builtin_elementwise_fma(g.xc[i], g.xc[i], h2{(_Float16)-0.5f, (_Float16)-0.5f});
-        else if constexpr (t == 2) g.q[i] = __builtin_elementwise_fma(g.sv[i], h2{(_Float16)-1.43921925f, (_Float16)-1.43921925f}, h2{(_Float16)1.90463124f, (_Float16)1.90463124f});
-        else if constexpr (t < 7) g.q[i] = __builtin_elementwise_fma(g.q[i], g.sv[i], h2{(_Float16)C[t - 3], (_Float16)C[t - 3]});
-        else if constexpr (t == 7) g.q[i] = __builtin_elementwise_fma(g.xc[i], g.q[i], h2{(_Float16)0.5f, (_Float16)0.5f});
+        constexpr float C[3] = {0.82089258f, -0.67178146f, 0.70430058f};
+        const h2 zero = {(_Float16)0.0f, (_Float16)0.0f}, one = {(_Float16)1.0f, (_Float16)1.0f};
+        if constexpr (t == 0) g.sv[i] = __builtin_elementwise_fma(g.x[i], g.x[i], h2{(_Float16)-0.5f, (_Float16)-0.5f});
+        else if constexpr (t == 1) g.q[i] = __builtin_elementwise_fma(g.sv[i], h2{(_Float16)2.74597983f, (_Float16)2.74597983f}, h2{(_Float16)-1.28256022f, (_Float16)-1.28256022f});
+        else if constexpr (t < 5) g.q[i] = __builtin_elementwise_fma(g.q[i], g.sv[i], h2{(_Float16)C[t - 2], (_Float16)C[t - 2]});
+        // Phi = the fma's result clamped to [0, 1]: the instruction's clamp bit
+        else if constexpr (t == 5) g.q[i] = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_elementwise_fma(g.x[i], g.q[i], h2{(_Float16)0.5f, (_Float16)0.5f}), zero), one);
         else g.x[i] = g.x[i] * g.q[i];
     }
 }
-// the pins of the steps that operation K completes (issued by the caller behind the gap's LDS requests: a pin directly behind a
-// packed instruction whose result it names costs an s_nop as well)
+// the pins of the steps that operation K completes (issued by the caller behind the gap's MFMA: a pin directly behind a packed
+// instruction whose result it names costs an s_nop as well)
 template <int K> TUP_DEVICE void gelu_pin(GeluState& g, bf16x8 (&hf)[2]) {
-    constexpr int b = K / 40, k = K % 40;
+    constexpr int b = K / 32, k = K % 32;
     if constexpr (k >= 4 && ((k - 4) & 3) == 3) {
         constexpr int t = (k - 4) >> 2;
-        if constexpr (t == 0) TUP_PIN4(g.xc);
-        else if constexpr (t == 1) TUP_PIN4(g.sv);
-        else if constexpr (t < 8) TUP_PIN4(g.q);
+        if constexpr (t == 0) TUP_PIN4(g.sv);
+        else if constexpr (t < 6) TUP_PIN4(g.q);
         else {
             TUP_PIN4(g.x);
             u32x4 pk;
@@ -574,6 +597,10 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
     auto dma_chunk_piece = [&](int c, int lds_off, int u) {
         if (wave < 4) { const int pc = mw + u; bs_dma(bs_rsrc(bp.wmlp), smem + lds_off + pc * 1024, lane16, c * TILE + (wave < 2 ? pc : pc - 12) * 1024); }
     };
+    // ... and inside the slots (bs_dma_on): pieces u = 0..3 and 4, 5 of a chunk off two bases each; waves 4-7 (bit 31): none
+    const __amdgpu_buffer_rsrc_t rs_mlp = bs_rsrc(bp.wmlp);
+    const uint32_t mlp_lds0 = __builtin_amdgcn_readfirstlane(sbase + (uint32_t)(mw * 1024) + (wave < 4 ? 0u : 0x80000000u));
+    const uint32_t mlp_src0 = __builtin_amdgcn_readfirstlane((uint32_t)((wave < 2 ? mw : mw - 12) * 1024));
     auto dma_chunk = [&](int c, int lds_off) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) dma_chunk_piece(c, lds_off, u);
@@ -645,64 +672,96 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
         uint32_t w2off[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) w2off[u] = sbase + (uint32_t)(r * 64 + (((2 * u + h) ^ ((r >> 2) & 3)) << 4));
-        int ri = 3;                                      // ring slot of the chunk whose fc1 the next slot runs (chunk 0: slot 3)
-        // DM: this slot also requests the chunks c + 2 and c + 3 (twelve pieces per wave of waves 0-3, every NM / 12-th gap)
-        auto slot = [&](auto par_, auto f1_, auto ge_, auto f2_, auto dm_, int c) {
-            constexpr int PAR = decltype(par_)::value;
-            constexpr bool F1 = decltype(f1_)::value, GE = decltype(ge_)::value, F2 = decltype(f2_)::value, DM = decltype(dm_)::value;
-            constexpr bool LNS = !F1 && !GE && F2;         // the last slot: tile t's accumulators are final behind MFMA 2 t + 1
-            // ring slots of the chunks c - 2, c, c + 2, c + 3 from the carried index ri = (c + 3) % 6 (a modulo per offset was ~30 scalar
+        int ri = 3;                                      // ring slot of the chunk whose fc1 the next pair starts with (chunk 0: slot 3)
+        // A PAIR of slots (chunks c, c + 1) is one stream of MFMAs with ONE fragment pipeline: the ring of fragment reads runs through
+        // the boundary between the two slots, and the second slot's mlp.0 bias is requested from inside the first once the GELU
+        // conversions have read the accumulators it goes into.  (Per slot: ~40 instructions of addresses, bias reads and a pipeline
+        // start less; the 0.33 k cycles per slot the stamps showed for them were mostly hidden by the SIMD's other wave.)
+        // DM (first slot only): the pair also requests the chunks c + 2 and c + 3 (twelve pieces per wave of waves 0-3)
+        auto pair = [&](auto A_, auto B_, int c) {
+            using A = decltype(A_); using B = decltype(B_);
+            static_assert(!B::DM && A::PAR == 0 && B::PAR == 1, "");
+            constexpr int NA = A::NM, NB = B::NM, NT = NA + NB;
+            // ring slots of the chunks c - 2 .. c + 3 from the carried index ri = (c + 3) % 6 (a modulo per offset was ~30 scalar
             // instructions at the top of every slot)
             auto wrap = [](int v) { return v >= 6 ? v - 6 : v; };
-            const int d0 = L_A + wrap(ri + 2) * CHUNK, d1 = L_A + wrap(ri + 3) * CHUNK;
-            // this slot's fragment addresses: mlp.0 tile of chunk c, mlp.2 tile of chunk c - 2
-            const uint32_t o1 = (uint32_t)(L_A + ri * CHUNK), o2 = (uint32_t)(L_A + wrap(ri + 4) * CHUNK + TILE);
-            ri = wrap(ri + 1);
-            uint32_t a1[4], a2[2];
+            // LDS bases and source offsets of the pieces this pair requests: chunk c + 2 -> ring slot ri + 2, chunk c + 3 -> ri + 3
+            uint32_t dl[2] = {0, 0}, ds[2] = {0, 0};
+            if constexpr (A::DM) {
+                dl[0] = mlp_lds0 + (uint32_t)(L_A + wrap(ri + 2) * CHUNK); dl[1] = mlp_lds0 + (uint32_t)(L_A + wrap(ri + 3) * CHUNK);
+                ds[0] = mlp_src0 + (uint32_t)((c + 2) * TILE); ds[1] = ds[0] + TILE;
+            }
+            // fragment addresses: [slot][..] = mlp.0 tile of chunk c / c + 1, mlp.2 tile of chunk c - 2 / c - 1
+            uint32_t a1[2][4], a2[2][2];
+            {
+                const uint32_t o1[2] = {(uint32_t)(L_A + ri * CHUNK), (uint32_t)(L_A + wrap(ri + 1) * CHUNK)};
+                const uint32_t o2[2] = {(uint32_t)(L_A + wrap(ri + 4) * CHUNK + TILE), (uint32_t)(L_A + wrap(ri + 5) * CHUNK + TILE)};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) a1[t] = woff[t] + o1;
+                for (int q = 0; q < 2; ++q) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) a2[u] = w2off[u] + o2;
+                    for (int t = 0; t < 4; ++t) a1[q][t] = woff[t] + o1[q];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) a2[q][u] = w2off[u] + o2[q];
+                }
+            }
+            ri = wrap(ri + 2);
             const uint32_t tb = tabh + (uint32_t)((T_B1 + c * 32) * 4);
             BS_STAMP(Q_M_DMA);
-            // fragment list of the slot: position n -> (fc1 K-step n / 2) on even n, (fc2 (rt, u) = (n / 4, (n / 2) & 1)) on odd n
-            constexpr int NM = (F1 && F2) ? 24 : 12;
-            auto frag = [&](auto n_) {
-                constexpr int n = decltype(n_)::value;
+            // fragment list: position g -> slot g / NA, n = g % NA; in a slot: (fc1 K-step n / 2) on even n, (fc2 (rt, u) = (n / 4, (n / 2) & 1))
+            // on odd n (a slot with only one of the two: K-step n)
+            auto frag = [&](auto g_) {
+                constexpr int g = decltype(g_)::value, q = g < NA ? 0 : 1, n = g < NA ? g : g - NA;
+                constexpr bool F1 = q == 0 ? A::F1 : B::F1, F2 = q == 0 ? A::F2 : B::F2;
                 constexpr bool is1 = F1 && (!F2 || (n & 1) == 0);
                 constexpr int k = (F1 && F2) ? n / 2 : n;
 #ifdef TUP_BSX_NOLDS          // timing experiment (wrong results): the MLP slots without their LDS fragment reads
-                return __builtin_bit_cast(bf16x8, u32x4{a1[k & 3], a2[k & 1], (uint32_t)n, 0u});
+                return __builtin_bit_cast(bf16x8, u32x4{a1[q][k & 3], a2[q][k & 1], (uint32_t)n, 0u});
 #else
-                if constexpr (is1) return lds_read_b128_asm_off(a1[k & 3], (k >> 2) * 4096);
-                else return lds_read_b128_asm_off(a2[k & 1], (k >> 1) * 2048);
+                if constexpr (is1) return lds_read_b128_asm_off(a1[q][k & 3], (k >> 2) * 4096);
+                else return lds_read_b128_asm_off(a2[q][k & 1], (k >> 1) * 2048);
 #endif
             };
             // fragments LA MFMAs ahead (ring of LA + 1): with eight waves reading 1 KB per MFMA the LDS runs half busy and a read takes
             // longer than the three gaps the attention loops allow
             constexpr int LA = 5, RS = LA + 1;
+            // the second slot's bias: requested in gap NBIAS of the first, behind that gap's fragment (the GELU conversions -- operations
+            // 0-3 and 32-35 of the slot's list -- are done with the accumulators)
+            constexpr int NBIAS = A::GE ? (35 * NA) / GELU_OPS + 1 : 1;
+            static_assert(!B::F1 || NBIAS + LA + 2 < NA, "the bias has landed before the second slot starts");
             bf16x8 wq[RS];
-            f32x4 b0, b1, b2, b3;
-            if constexpr (F1) { b0 = lds_read_f4_off(tb, 0); b1 = lds_read_f4_off(tb, 16); b2 = lds_read_f4_off(tb, 32); b3 = lds_read_f4_off(tb, 48); }
+            f32x4 b0, b1, b2, b3, c0, c1, c2, c3;
+            if constexpr (A::F1) { b0 = lds_read_f4_off(tb, 0); b1 = lds_read_f4_off(tb, 16); b2 = lds_read_f4_off(tb, 32); b3 = lds_read_f4_off(tb, 48); }
             static_for<LA>([&](auto i_) { wq[decltype(i_)::value] = frag(i_); });
             lds_wait<LA - 1>();
             FENCE();
-            if constexpr (F1) acc1[PAR] = acc_from4(b0, b1, b2, b3);
-            static_for<NM>([&](auto n_) {
-                constexpr int n = decltype(n_)::value;
+            if constexpr (A::F1) acc1[0] = acc_from4(b0, b1, b2, b3);
+            static_for<NT>([&](auto g_) {
+                constexpr int g = decltype(g_)::value, q = g < NA ? 0 : 1, n = g < NA ? g : g - NA;
+                constexpr int NM = q == 0 ? NA : NB, PAR = q;
+                constexpr bool F1 = q == 0 ? A::F1 : B::F1, F2 = q == 0 ? A::F2 : B::F2, GE = q == 0 ? A::GE : B::GE;
+                constexpr bool DM = q == 0 && A::DM, LNS = q == 0 ? A::LNS : B::LNS;
                 constexpr bool is1 = F1 && (!F2 || (n & 1) == 0);
                 constexpr int k = (F1 && F2) ? n / 2 : n;
-                if constexpr (is1) acc1[PAR] = mfma32(wq[n % RS], tf[k], acc1[PAR]);
-                else R[k >> 1] = mfma32h(wq[n % RS], hfr[PAR][k & 1], R[k >> 1]);
+                if constexpr (g == NA && B::F1) acc1[1] = acc_from4(c0, c1, c2, c3);
+                if constexpr (is1) acc1[PAR] = mfma32(wq[g % RS], tf[k], acc1[PAR]);
+                else R[k >> 1] = mfma32h(wq[g % RS], hfr[PAR][k & 1], R[k >> 1]);
+                FENCE();                                   // the MFMA heads its gap (left to itself hipcc pairs the MFMAs of two gaps up)
                 // Order of a gap: the MFMA; the pins of the PREVIOUS gap's GELU results (an asm right behind the packed instruction whose
                 // result it names, or right in front of one that reads it, costs an s_nop); the LDS request; the wait; this gap's GELU work
 #ifndef TUP_BSX_NOGELU
                 if constexpr (GE && n > 0) gelu_pins<(GELU_OPS * (n - 1)) / NM, (GELU_OPS * n) / NM>(gs, hfr[1 - PAR]);
 #endif
-                if constexpr (n + LA < NM) wq[(n + LA) % RS] = frag(std::integral_constant<int, n + LA>{});
-                // (one wait per TWO gaps: at even n the fragments of MFMAs n + 1 and n + 2 are made ready -- every instruction of a gap is an
-                // issue slot of the SIMD)
-                if constexpr ((n & 1) == 0 && n + 1 < NM) lds_wait<(NM - 3 - n < LA - 2 ? (NM - 3 - n < 0 ? 0 : NM - 3 - n) : LA - 2)>();
+                if constexpr (g + LA < NT) wq[(g + LA) % RS] = frag(std::integral_constant<int, g + LA>{});
+                if constexpr (B::F1 && g == NBIAS) {
+                    c0 = lds_read_f4_off(tb, 128); c1 = lds_read_f4_off(tb, 128 + 16); c2 = lds_read_f4_off(tb, 128 + 32); c3 = lds_read_f4_off(tb, 128 + 48);
+                }
+                // (one wait per TWO gaps: at even g the fragments of MFMAs g + 1 and g + 2 are made ready -- every instruction of a gap is an
+                // issue slot of the SIMD; the four bias reads count while they are younger than the fragment of MFMA g + 2)
+                if constexpr ((g & 1) == 0 && g + 1 < NT) {
+                    constexpr int FR = NT - 3 - g < LA - 2 ? (NT - 3 - g < 0 ? 0 : NT - 3 - g) : LA - 2;
+                    constexpr int BI = (B::F1 && g + 2 - LA <= NBIAS && NBIAS <= g) ? 4 : 0;
+                    lds_wait<FR + BI>();
+                }
 #ifndef TUP_BSX_NOGELU        // timing experiment (wrong results): ... without the GELU arithmetic (fc1's accumulators kept alive)
                 if constexpr (GE) gelu_ops<(GELU_OPS * n) / NM, (GELU_OPS * (n + 1)) / NM>(gs, acc1[1 - PAR], hfr[1 - PAR]);
 #else
@@ -711,7 +770,8 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
 #ifndef TUP_BSX_NODMA         // ... without the weight DMA requests (stale weights)
                 if constexpr (DM && n % (NM / 12) == NM / 12 - 1) {
                     constexpr int pi = n / (NM / 12);
-                    if constexpr (pi < 6) dma_chunk_piece(c + 2, d0, pi); else dma_chunk_piece(c + 3, d1, pi - 6);
+                    constexpr int dq = pi / 6, u = pi % 6;
+                    bs_dma_on<(u & 3) * 1024>(rs_mlp, dl[dq] + (u >> 2) * 4096, lane16, ds[dq] + (u >> 2) * 4096);
                 }
 #endif
                 if constexpr (LNS && n >= 4) ln_stats_ops<16 * (n & 1), 16 * (n & 1) + 16>(ln1, R[(n - 4) >> 1]);
@@ -722,22 +782,18 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
             });
             BS_STAMP(Q_MLP);
         };
-        // One barrier per PAIR of slots: at the start of pair k (slots 2k, 2k + 1) the chunks 2k + 2 and 2k + 3 are requested into the
-        // ring slots of chunks 2k - 4 and 2k - 3 (whose mlp.2 tiles were last read in slots 2k - 2 and 2k - 1); they are needed a pair later.
+        // One barrier per pair: at the start of pair k (slots 2k, 2k + 1) the chunks 2k + 2 and 2k + 3 are requested into the ring
+        // slots of chunks 2k - 4 and 2k - 3 (whose mlp.2 tiles were last read in slots 2k - 2 and 2k - 1); they are needed a pair later.
         auto pair_end = [&]() { barrier_all(); BS_STAMP(Q_BAR_MLP); };
-        using T_ = std::true_type; using F_ = std::false_type;
-        constexpr std::integral_constant<int, 0> P0{}; constexpr std::integral_constant<int, 1> P1{};
-        slot(P0, T_{}, F_{}, F_{}, T_{}, 0);
-        slot(P1, T_{}, T_{}, F_{}, F_{}, 1);
+        pair(MlpSlot<0, true, false, false, true>{}, MlpSlot<1, true, true, false, false>{}, 0);
         pair_end();
 #pragma unroll 1
         for (int c = 2; c < 22; c += 2) {
-            slot(P0, T_{}, T_{}, T_{}, T_{}, c); slot(P1, T_{}, T_{}, T_{}, F_{}, c + 1);
+            pair(MlpSlot<0, true, true, true, true>{}, MlpSlot<1, true, true, true, false>{}, c);
             pair_end();
         }
-        slot(P0, T_{}, T_{}, T_{}, F_{}, 22); slot(P1, T_{}, T_{}, T_{}, F_{}, 23);
-        slot(P0, F_{}, T_{}, T_{}, F_{}, 24);
-        slot(P1, F_{}, F_{}, T_{}, F_{}, 25);
+        pair(MlpSlot<0, true, true, true, false>{}, MlpSlot<1, true, true, true, false>{}, 22);
+        pair(MlpSlot<0, false, true, true, false>{}, MlpSlot<1, false, false, true, false>{}, 24);
         BS_STAMP(Q_MLP);
     }
     }   // blk

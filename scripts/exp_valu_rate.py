@@ -20,5 +20,7 @@ print(f"bare MFMAs: one wave/SIMD {max(base1) / (4 * reps):.1f} cycles per MFMA;
 for k, n in enumerate(names):
     a1 = run(k, 1, 0, 4); a2 = run(k, 1, 0, 8)
     m1 = run(k, 1, 1, 4); m2 = run(k, 1, 1, 8); m1b = run(k, 2, 1, 4); m2b = run(k, 2, 1, 8)
+    few = "  ".join(f"{c}: {max(run(k, 100 + c, 1, 4)) / (4 * reps):5.1f} / {max(run(k, 100 + c, 1, 8)) / (4 * reps):5.1f}" for c in (2, 4, 6))
+    print(f"{n:20s} MFMA + c fillers, gap of one wave (1 wave/SIMD / 2 waves/SIMD): {few}")
     print(f"{n:20s} alone: {max(a1) / (32 * reps):5.2f} cyc/instr (1 wave/SIMD) {max(a2) / (32 * reps):5.2f} (2 waves, each)   "
           f"| MFMA + 8 fillers: {max(m1) / (4 * reps):6.1f} / gap (1 wave) {max(m2) / (4 * reps):6.1f} (2 waves)   | MFMA + 16: {max(m1b) / (4 * reps):6.1f} {max(m2b) / (4 * reps):6.1f}")

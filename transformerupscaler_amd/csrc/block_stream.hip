@@ -289,7 +289,12 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
     // store / load instruction then moves one contiguous KB.  (In the window layout a lane's 64 bytes are a row apart from its
     // neighbour's: 24 such stores per wave ran at 7 bytes per cycle and CU -- 28 k cycles per block in the stamps.)  The window
     // layout is read at the start and written at the end of the launch, through an LDS transpose (full 128-byte lines per row).
-    float* xpark = xio + (size_t)row0 * 192 + lane * 4;
+    // (addressed as a scalar base + a 32-bit lane offset: as 64-bit per-lane pointers every access beyond the instruction's immediate
+    // offset range cost two or three vector additions)
+    typedef __attribute__((address_space(1))) char* gptr_b;
+    gptr_b xpark_b = (gptr_b)(xio + (size_t)row0 * 192);
+    asm volatile("" : "+s"(xpark_b));
+    const uint32_t lane16u = (uint32_t)lane * 16;
     // the block's pointers as opaque scalar values: left as kernel-argument loads, hipcc re-loads them in front of every DMA piece
     // (s_load + s_waitcnt lgkmcnt(0): a wait that also drains the LDS fragment reads in flight)
     struct { const char* wqk; const char* wv; const char* wproj; const char* wmlp; const float* tab; const float* sbias; } bp;
@@ -393,12 +398,16 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
     // ---- attention half ----
     f32x16 accqk, accv, S[2], O;
     bf16x8 Qf, Kfo, Kfp, Vfo[2], Vfp[2], P[4], Ofr[4];
-    const gptr_f sbp = (gptr_f)bp.sbias + (size_t)lane * 16;
+    // relative position bias of (head, query half hf, key half kt): 4 KB each, 64 bytes per lane; scalar base per (head, kt)
+    typedef const __attribute__((address_space(1))) char* gptr_c;
+    const uint32_t lane64u = (uint32_t)lane * 64;
     auto load_sbias = [&](int hd) {                         // S[0] <- bias of (own keys), S[1] <- (partner's keys)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int kt = t == 0 ? hf : 1 - hf;
-            const gptr_f4 p4 = (gptr_f4)(sbp + (size_t)(((hd * 2 + hf) * 2 + kt) * 64) * 16);
+            gptr_c sb = (gptr_c)bp.sbias + (size_t)(((hd * 2 + hf) * 2 + kt) * 4096);
+            asm volatile("" : "+s"(sb));
+            const gptr_f4 p4 = (gptr_f4)(sb + lane64u);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 v = p4[m];
@@ -441,7 +450,9 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
             if constexpr (g + 1 < 12) tf[g + 1] = ln_frag<(g + 1) & 1>(R[(g + 1) >> 1], ln_rstd, ln_shift);
             {
                 constexpr int rt = g >> 2, m = g & 3;
-                if (active) *reinterpret_cast<f32x4*>(xpark + (rt * 4 + m) * 256) = f32x4{R[rt][4 * m], R[rt][4 * m + 1], R[rt][4 * m + 2], R[rt][4 * m + 3]};
+                gptr_b pb = xpark_b + rt * 4096;         // one scalar base per 4 KB (the immediate offset's range)
+                asm volatile("" : "+s"(pb));
+                if (active) *(__attribute__((address_space(1))) f32x4*)(pb + m * 1024 + lane16u) = f32x4{R[rt][4 * m], R[rt][4 * m + 1], R[rt][4 * m + 2], R[rt][4 * m + 3]};
             }
             FENCE();
         });
@@ -584,7 +595,9 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
     // loads at once sat 8 k cycles in the issue queue of the critical waves: the CU's 192 KB come back at the L2 / fabric rate)
     auto load_park = [&](auto rt_, auto m_) {
         constexpr int rt = decltype(rt_)::value, m = decltype(m_)::value;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xpark + (rt * 4 + m) * 256);
+        gptr_b pb = xpark_b + rt * 4096;
+        asm volatile("" : "+s"(pb));
+        const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)(pb + m * 1024 + lane16u);
 #pragma unroll
         for (int e = 0; e < 4; ++e) R[rt][4 * m + e] = v[e];
     };

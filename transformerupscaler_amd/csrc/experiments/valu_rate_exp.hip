@@ -3,9 +3,9 @@
 #include "../common.h"
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 namespace {
-template <int KIND> __device__ __forceinline__ void filler(float (&a)[8], float b, float c, uint32_t& sc, u32x4 (&q)[4], uint32_t lds_a) {
+template <int KIND, int CNT = 8> __device__ __forceinline__ void filler(float (&a)[8], float b, float c, uint32_t& sc, u32x4 (&q)[4], uint32_t lds_a) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < CNT; ++i) {
         if constexpr (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
         else if constexpr (KIND == 1) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
         else if constexpr (KIND == 2) asm volatile("v_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
@@ -26,7 +26,7 @@ template <int KIND> __device__ __forceinline__ void filler(float (&a)[8], float 
         else if constexpr (KIND == 17) asm volatile("s_waitcnt lgkmcnt(15)");
     }
 }
-template <int KIND, int NF8, bool MF> __global__ __launch_bounds__(512) void rate_kernel(unsigned long long* out, float seed, int reps)
+template <int KIND, int NF8, bool MF, int CNT = 8> __global__ __launch_bounds__(512) void rate_kernel(unsigned long long* out, float seed, int reps)
 {
     float a[8];
 #pragma unroll
@@ -43,7 +43,7 @@ template <int KIND, int NF8, bool MF> __global__ __launch_bounds__(512) void rat
         for (int u = 0; u < 4; ++u) {
             if constexpr (MF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(fa), "v"(fb));
 #pragma unroll
-            for (int k = 0; k < NF8; ++k) filler<KIND>(a, seed, seed, sc, q, lds_a);
+            for (int k = 0; k < NF8; ++k) filler<KIND, CNT>(a, seed, seed, sc, q, lds_a);
         }
     }
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
@@ -64,7 +64,8 @@ extern "C" int tup_exp_valu_rate(unsigned long long* out, int kind, int nf8, int
 {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define L(K, N, M) if (kind == K && nf8 == N && mf == M) { rate_kernel<K, N, (M != 0)><<<dim3(256), dim3(64 * waves), 0, st>>>(out, 1.0f, reps); return (int)hipGetLastError(); }
-#define LK(K) L(K, 1, 0) L(K, 1, 1) L(K, 0, 1) L(K, 2, 1)
+#define L2(K, C) if (kind == K && nf8 == 100 + C && mf == 1) { rate_kernel<K, 1, true, C><<<dim3(256), dim3(64 * waves), 0, st>>>(out, 1.0f, reps); return (int)hipGetLastError(); }
+#define LK(K) L(K, 1, 0) L(K, 1, 1) L(K, 0, 1) L(K, 2, 1) L2(K, 2) L2(K, 4) L2(K, 6)
     LK(0) LK(1) LK(2) LK(3) LK(4) LK(5) LK(6) LK(7) LK(8) LK(9) LK(10) LK(11) LK(12) LK(13) LK(14) LK(15) LK(16) LK(17)
     return 1;
 }

@@ -149,3 +149,39 @@ def test_stream_index_maps_are_permutations():
         rows = [_rho(i, h) for i in range(16)]
         ch = och[3][rows].tolist()
         assert ch == list(range(96 + 16 * h, 96 + 16 * h + 16)), ch
+
+
+def test_stream_gelu_polynomial_from_the_kernel_source():
+    """The GELU of tup_blocks_stream_fwd (csrc/block_stream.hip gelu_op; reference nn.GELU(), model.py:100-104): the coefficients are read
+    out of the kernel source and the eight packed-fp16 instructions per pair of values are replayed in numpy with one fp16 rounding
+    per fma -- error bound over |x| <= 12, exact saturation outside (the clamp bit of the last fma is the only clamp), no NaN from
+    the overflow of the Horner chain."""
+    import os
+    import re
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(os.path.dirname(__file__), "..", "transformerupscaler_amd", "csrc", "block_stream.hip")).read()
+    body = src[src.index("TUP_DEVICE void gelu_op("):src.index("template <int K> TUP_DEVICE void gelu_pin(")]
+    c_tail = [float(v) for v in re.search(r"constexpr float C\[3\] = \{([^}]*)\}", body).group(1).replace("f", "").split(",")]
+    lead = [float(v) for v in re.findall(r"\(_Float16\)(-?[0-9.]+)f", body[body.index("t == 1"):body.index("t < 5")])]
+    assert len(c_tail) == 3 and len(lead) == 4 and lead[0] == lead[1] and lead[2] == lead[3]
+    coef = [lead[0], lead[2]] + c_tail                                     # highest degree first
+    f16 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+    fma = lambda a, b, c: f16(np.float32(a) * np.float32(b) + np.float32(c))
+    x = np.concatenate([np.linspace(-12, 12, 96001), [-1e4, -300.0, -64.0, 64.0, 300.0, 1e4]]).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        u = f16(x / 4)
+        s = fma(u, u, -0.5)
+        q = fma(s, f16(coef[0]), f16(coef[1]))
+        for c in coef[2:]:
+            q = fma(q, s, f16(c))
+        phi = np.clip(fma(u, q, 0.5), 0.0, 1.0)                              # v_pk_fma_f16 ... clamp
+        got = f16(u * phi) * 4
+    assert np.isfinite(got).all()
+    want = x * 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    err = np.abs(got - want)
+    inner = np.abs(x) <= 12
+    print("stream GELU: max |error| %.2e on |x| <= 12" % err[inner].max())
+    assert err[inner].max() <= 5e-3
+    assert (phi[x >= 4] == 1).all() and (phi[x <= -4] == 0).all()             # exact saturation, overflow included
+    assert (got[~inner & (x < 0)] == 0).all() and np.allclose(got[~inner & (x > 0)], f16(f16(x[~inner & (x > 0)] / 4)) * 4)

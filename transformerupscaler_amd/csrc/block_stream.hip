@@ -24,7 +24,7 @@
 //   * O^T's registers pack into the B fragment of K-step "head" of the proj; the hidden tile's into the K-steps of mlp.2.
 // LDS (one workgroup per CU): tables | region A: q|k ring [2] + v ring [2] (12 KB tiles, byte-exact images, linear DMA) | region B:
 // K / V fragment exchange | the attention outputs of heads 0-7 (8 KB per wave; heads 8-11 stay in registers).  The proj weight
-// then takes regions A + B, the MLP weight ring (5 x 24 KB: mlp.0 chunk + mlp.2 chunk of 32 hidden units) all of it.
+// then takes regions A + B, the MLP weight ring (6 x 24 KB: mlp.0 chunk + mlp.2 chunk of 32 hidden units) all of it.
 // The residual stream leaves the registers once per block (stored after LayerNorm1, re-read into the proj accumulators).
 #include "common.h"
 #include <stdlib.h>
@@ -188,17 +188,19 @@ template <int K0, int K1> TUP_DEVICE void softmax_ops(SmState& st, f32x16 (&S)[2
     static_for<(K1 > K0 ? K1 - K0 : 0)>([&](auto k) { softmax_op<K0 + decltype(k)::value>(st, S, P, h0); });
 }
 
-// ---- GELU of a hidden chunk (16 accumulator values per lane = 8 fp16 pairs) as 80 micro-operations: two batches of four chains ----
-// (the form of common.h gelu16_batch: x' = x / 4 in, gelu(x) / 4 = x' (0.5 + xc R(xc^2 - 0.5)) out, xc = clamp(x', +-1), with R of
-// degree FIVE here: every vector instruction of this kernel costs its issue slot beside the MFMAs (the GELU arithmetic is 90 of the
-// launch's 790 us, timing build TUP_BSX_NOGELU), and in fp16 arithmetic the degree-5 fit -- same constraints, pinned tail -- is as good as
-// the degree-6 one: max |error| 4.2e-3 vs 3.9e-3 (the fp16 rounding of the Horner chain, not the fit), rms 7.3e-4 vs 4.6e-4 under
-// N(0, 1.5); the bf16 hidden tile of rounds 1-2 had 1.6e-2 / 2.4e-3.)  op 40 b + k: k < 4 convert pair k; then step-major:
-// k = 4 + 4 t + i, step t < 9 of chain i (t = 0: the clamp, two instructions).
+// ---- GELU of a hidden chunk (16 accumulator values per lane = 8 fp16 pairs) as 64 micro-operations: two batches of four chains ----
+// u = x / 4 in (the 1/4 rides in the packed mlp.0 weight and bias), gelu(x) / 4 = u Phi out (mlp.2 carries the 4), with
+//     Phi(x) ~ clamp01(1/2 + u q(u^2 - 1/2)),  q of degree 4,
+// in packed fp16.  The clamp is the clamp bit of the last fma and there is none on the input: q is fitted (minimax on the GELU's
+// own error over |x| <= 12, scripts/fit_gelu.py) with a positive leading coefficient, so that beyond |x| ~ 3.6 the argument runs
+// monotonically out of [0, 1] (overflow to +-inf included) and the clamp returns the exact 0 or 1.  fp16 evaluation: max |error|
+// 3.9e-3, rms 8.0e-4 under N(0, 1.5) (rounds 3-4's degree 5 with an explicit max / min on the input: 4.2e-3 / 7.3e-4, 11 instead
+// of 8 instructions per pair of values; the bf16 hidden tile of rounds 1-2 had 1.6e-2 / 2.4e-3).  Every vector instruction of this
+// kernel is charged on the SIMD's vector port: the 88 instructions of the previous form cost 8-11 % of the launch
+// although four of them sat behind every MFMA.  op 32 b + k: k < 4 convert pair k; then step-major: k = 4 + 4 t + i, step t < 7 of
+// chain i (u^2 - 1/2; the Horner start; three Horner steps; Phi; u Phi).
 // Pinning: hipcc sinks a chain nothing in its slot consumes out of the MFMA stream (a GELU phase of its own in the loop latch;
-// sched_barrier binds only the machine scheduler), so the four results of a step pass through ONE empty volatile asm behind the
-// step's last operation.  (One asm per result cost an s_nop each -- hipcc pads a packed instruction that follows an inline asm --
-// and an asm between the conversion and the clamp a canonicalising v_pk_max per value: 47 + 32 instructions per pair of slots.)
+// sched_barrier binds only the machine scheduler), so a step's results pass through an empty volatile asm behind the NEXT MFMA.
 constexpr int GELU_OPS = 64;                  // = its instructions: 2 x (4 conversions + 7 steps x 4 packed pairs)
 struct GeluState { h2 x[4], sv[4], q[4]; };
 // One value of a step's four is pinned: with the slot one basic block that holds the whole step in its gap, and the pinned value's

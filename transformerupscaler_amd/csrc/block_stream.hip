@@ -101,7 +101,8 @@ TUP_DEVICE void bs_dma(__amdgpu_buffer_rsrc_t r, char* lds_dst, uint32_t lane16,
 #pragma clang diagnostic ignored "-Winline-asm"
 template <int OFF> TUP_DEVICE void bs_dma_on(__amdgpu_buffer_rsrc_t rs, uint32_t lds_base, uint32_t lane16, uint32_t soff) {
     static_assert(OFF >= 0 && OFF < 4096, "12-bit immediate offset");
-    asm volatile("s_bitcmp1_b32 %0, 31\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds\n1:"
+    // (s_nop: a scalar write of M0 needs one wait state before an LDS-DMA instruction reads it -- hipcc pads its own the same way)
+    asm volatile("s_bitcmp1_b32 %0, 31\n\ts_cbranch_scc1 1f\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds\n1:"
                  :: "s"(lds_base), "v"(lane16), "s"(rs), "s"(soff), "n"(OFF) : "memory", "scc", "m0");
 }
 #pragma clang diagnostic pop

@@ -149,9 +149,10 @@ int tup_patch_embed_fwd(const void* feat, const void* Wt, const float* bias, flo
                         int B, int H, int W, void* stream);
 
 /* window_reverse + crop + patch_unembed ConvTranspose2d(192,64,k8,s8) + crop + skip add:
- * model.py:292-309.  x fp32 window layout; Wt bf16 [4096][192], n = (i*8+j)*64+o; bias fp32 [64];
+ * model.py:292-309.  x window layout, fp32 (x_bf16 = 0) or bf16 (x_bf16 = 1: tup_blocks_stream_fwd's out_bf16 -- the GEMM rounds an
+ * fp32 x to the same bf16 values on load); Wt bf16 [4096][192], n = (i*8+j)*64+o; bias fp32 [64];
  * skip/out bf16 NHWC [B][H][W][64]. */
-int tup_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip,
+int tup_patch_unembed_fwd(const void* x, int x_bf16, const void* Wt, const float* bias, const void* skip,
                           void* out, int B, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -426,10 +427,12 @@ int tup_fused_blocks32_fwd(float* x, const void* const* table, int nblk, int nwi
 
 /* The same loop (model.py:288-289; blocks :153-172) as the streamed 32x32x16-MFMA kernel (csrc/block_stream.hip): one workgroup of
  * eight waves carries four windows through all nblk blocks; LayerNorm / softmax / GELU instructions sit between the matrix
- * instructions of the same wave.  x fp32 [64*nwin][192] in place; table: HOST array [nblk][7] of device pointers, per block the
+ * instructions of the same wave.  x fp32 [64*nwin][192]; out_bf16 = NULL: in place; out_bf16 != NULL: the result goes there as bf16
+ * [64*nwin][192] (round to nearest even) and x is left holding the kernel's parked intermediate -- for tup_patch_unembed_fwd with
+ * x_bf16 = 1, which then reads half the bytes for the same operand.  table: HOST array [nblk][7] of device pointers, per block the
  * tensors of packing.pack_stream_block: wqk bf16 [12][3][32][64], wv bf16 [6][3][32][64], wproj bf16 [6][3][32][64],
  * w1 bf16 [24][3][32][64], w2 fp16 [24][6][32][32], tab fp32 [1536], sbias fp32 [12][2][2][64][16]. */
-int tup_blocks_stream_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream);
+int tup_blocks_stream_fwd(float* x, void* out_bf16, const void* const* table, int nblk, int nwin, void* stream);
 
 /* Re-packing the weights after an optimizer step (training; replaces the torch index / permute / cat / cast calls of
  * packing.py that follow reference train.py:139 `optimizer.step()`): dst[i] = map[i] < 0 ? 0 : concat(src[0..nparam-1])[map[i]].

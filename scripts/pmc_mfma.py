@@ -24,7 +24,7 @@ KERNELS_BY_MODE = {
         "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip"),
         "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip"),
         "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip"),
-        "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip"),
+        "patch_unembed": ("gemm_panel2_kernel<0, 4>", "gemm_tokens.hip"),          # bf16 tokens from the streamed block kernel
     },
     "train": {   # FastTransformer training step (BASELINE configs[2] per rank)
         "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip"),

@@ -21,7 +21,7 @@ KEYS = {
         "stream_block": ("blocks_stream_kernel", "block_stream.hip", 6 * 1920 * 64 * 192 * 4 * 2),
         "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 8 * F64),
         "tail": ("tail_stream_r2_kernel<true>", "tail_stream.hip", 8 * 3 * (720 * 1280 + 1440 * 2560 + 1080 * 1920) * 4),
-        "patch_unembed": ("gemm_panel2_kernel<1, 4>", "gemm_tokens.hip", 1920 * 64 * 192 * 4 + 2 * 8 * F64),
+        "patch_unembed": ("gemm_panel2_kernel<0, 4>", "gemm_tokens.hip", 1920 * 64 * 192 * 2 + 2 * 8 * F64),      # bf16 tokens (the streamed block kernel's out_bf16), skip in, map out
         "patch_embed": ("patch_embed_kernel<3, 2, 3>", "gemm_tokens.hip", 8 * F64 + 1920 * 64 * 192 * 4),
         "branch_a_5x5": ("bra_rows_persistent_kernel", "conv3x3_c64.hip", 8 * F64 + 8 * 3 * 1440 * 2560 * 4),
         "conv1": ("conv3x3_c3_persistent_kernel", "conv_thin.hip", 8 * 3 * 720 * 1280 * 4 + 8 * F64),

@@ -800,6 +800,33 @@ def _stream_operands(dev, raw):
                                                               raw["w1"], raw["b1"], raw["gm2"], raw["bt2"], raw["w2"], raw["b2"]))
 
 
+@pytest.mark.parametrize("nwin", [1, 5, 64, 540])
+def test_stream_block_bf16_tokens(dev, nwin):
+    """tup_blocks_stream_fwd with out_bf16: the result as bf16 tokens = round-to-nearest-even of the in-place fp32 result, bit for
+    bit (1 and 5 windows: inactive waves of the four-window workgroup must not write); and tup_patch_unembed_fwd (model.py:292-309)
+    reading those bf16 tokens = the same output as reading the fp32 ones (its GEMM rounds them on load)."""
+    from transformerupscaler_amd import ops, packing
+    raw, _ = _block_operands(dev, nwin)
+    x = raw["x"].to(dev)
+    tab = ops.stream_table([_stream_operands(dev, raw)])
+    want = ops.blocks_stream(x.clone(), tab)
+    guard = torch.full((64, 192), 7.0, dtype=torch.bfloat16, device=dev)
+    got = ops.blocks_stream(x.clone(), tab, out_bf16=True)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (nwin * 64, 192)
+    assert torch.equal(got, want.to(torch.bfloat16))
+    assert (guard == 7.0).all()
+    if nwin == 540:                                           # 4 images of 540 x 960 / 8 = 68 x 120 tokens -> 9 x 15 windows
+        B, H, W = 4, 540, 960
+        g = torch.Generator().manual_seed(5)
+        wu = torch.randn((192, 64, 8, 8), generator=g) * 0.05
+        bu = torch.randn(64, generator=g) * 0.1
+        skip = torch.randn((B, H, W, 64), generator=g).to(torch.bfloat16).to(dev)
+        wt = packing.pack_patch_unembed(wu).to(dev)
+        a = ops.patch_unembed(want, wt, bu.to(dev), skip)
+        b = ops.patch_unembed(got, wt, bu.to(dev), skip)
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("nwin", [1, 3, 4, 5, 64, 1920])
 def test_stream_block_vs_torch(dev, nwin):
     """tup_blocks_stream_fwd (the streamed 32x32x16 whole-block kernel, model.py:153-172) with one block against torch fp32 on

@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 P = c_void_p
 I = c_int
@@ -37,7 +37,7 @@ SIGNATURES = {
     "tup_ln_gemm_fwd": [P, P, P, P, P, P, I, I, P],
     "tup_fused_mlp_fwd": [P, P, P, P, P, P, P, I, P],
     "tup_patch_embed_fwd": [P, P, P, P, I, I, I, P],
-    "tup_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
+    "tup_patch_unembed_fwd": [P, I, P, P, P, P, I, I, I, P],
     # ResidualTransformer
     "tup_rt_patch_embed_fwd": [P, P, P, P, P, I, I, I, P],
     "tup_rt_patch_unembed_fwd": [P, P, P, P, P, I, I, I, P],
@@ -61,7 +61,7 @@ SIGNATURES = {
     "tup_fused_attn_block_fwd": [P, P, P, P, P, P, P, P, I, P],
     "tup_fused_block_fwd": [P] * 10 + [I, P],
     "tup_fused_blocks32_fwd": [P, P, I, I, P],
-    "tup_blocks_stream_fwd": [P, P, I, I, P],
+    "tup_blocks_stream_fwd": [P, P, P, I, I, P],
     "tup_clock_probe": [P, P],
     "tup_pack_gather": [P, P, I, P, P, c_longlong, I, P],
     "tup_adam_step": [P, P, I, P],

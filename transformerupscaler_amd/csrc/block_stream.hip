@@ -262,7 +262,7 @@ TUP_DEVICE unsigned long long bs_now() {
 }
 
 template <bool STAMPS>
-__global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restrict__ xio, int nwin, const StreamTable tbl, int nblk)
+__global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restrict__ xio, bf16_t* __restrict__ xout16, int nwin, const StreamTable tbl, int nblk)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t sbase = lds_addr(smem);
@@ -813,7 +813,32 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
         BS_STAMP(Q_MLP);
     }
     }   // blk
-    {   // R -> x in the window layout, through the wave's LDS scratch (every LDS reader of the launch is behind the last barrier)
+    if (xout16 != nullptr) {
+        // R -> bf16 tokens [nwin * 64][192] in the window layout (the operand patch_unembed's GEMM rounds x to anyway; x itself then
+        // only holds the parked stream): two passes of three tiles through the wave's LDS scratch as a linear image of 32 half rows
+        // of 192 bytes, stored 16 bytes per lane
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+        const int win = blockIdx.x * 4 + (wave >> 1);
+        char* scr = smem + L_OF + wave * 8192;
+        char* og = reinterpret_cast<char*>(xout16) + (size_t)((win < nwin ? win : nwin - 1) * 64 + 32 * (wave & 1)) * 384;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const f32x16& a = R[3 * q + t];
+                *reinterpret_cast<bf16x8*>(scr + r * 192 + t * 64 + h * 32) = pack8(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+                *reinterpret_cast<bf16x8*>(scr + r * 192 + t * 64 + h * 32 + 16) = pack8(a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15]);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int b = j * 1024 + lane * 16, row = b / 192, col = b - row * 192;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(scr + b);
+                if (win < nwin) *reinterpret_cast<u32x4*>(og + (size_t)row * 384 + q * 192 + col) = v;
+            }
+        }
+    } else {   // R -> x in the window layout, through the wave's LDS scratch (every LDS reader of the launch is behind the last barrier)
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -847,10 +872,12 @@ __global__ __launch_bounds__(BS_NT, 2) void blocks_stream_kernel(float* __restri
 
 }  // namespace
 
-// nblk (<= 8) consecutive WindowTransformerBlocks, in place, in one launch (the loop of model.py:288-289): x fp32 [nwin * 64][192] in
-// window order; table: HOST array [nblk][7] of device pointers = the tensors of packing.pack_stream_block (wqk, wv, wproj, w1, w2,
-// tab, sbias).
-extern "C" int tup_blocks_stream_fwd(float* x, const void* const* table, int nblk, int nwin, void* stream)
+// nblk (<= 8) consecutive WindowTransformerBlocks in one launch (the loop of model.py:288-289): x fp32 [nwin * 64][192] in window
+// order; table: HOST array [nblk][7] of device pointers = the tensors of packing.pack_stream_block (wqk, wv, wproj, w1, w2, tab,
+// sbias).  out_bf16 == nullptr: the result replaces x.  out_bf16 != nullptr: the result is written there as bf16 [nwin * 64][192]
+// (round to nearest even of the same values) and x is left holding the kernel's parked intermediate -- for a consumer that rounds
+// the tokens to bf16 anyway (tup_patch_unembed_fwd), which then reads half the bytes.
+extern "C" int tup_blocks_stream_fwd(float* x, void* out_bf16, const void* const* table, int nblk, int nwin, void* stream)
 {
     if (nwin <= 0 || nblk <= 0) return 0;
     if (nblk > BS_MAX_BLK || table == nullptr) return (int)hipErrorInvalidValue;
@@ -864,13 +891,13 @@ extern "C" int tup_blocks_stream_fwd(float* x, const void* const* table, int nbl
 #ifdef TUP_DIAG
     if (getenv("TUP_BS_STAMPS")) {
         TUP_SET_DYN_LDS(blocks_stream_kernel<true>, BS_LDS);
-        blocks_stream_kernel<true><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, nwin, t, nblk);
+        blocks_stream_kernel<true><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, reinterpret_cast<bf16_t*>(out_bf16), nwin, t, nblk);
         TUP_CHECK_LAUNCH();
         return 0;
     }
 #endif
     TUP_SET_DYN_LDS(blocks_stream_kernel<false>, BS_LDS);
-    blocks_stream_kernel<false><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, nwin, t, nblk);
+    blocks_stream_kernel<false><<<dim3(nwg), dim3(BS_NT), BS_LDS, reinterpret_cast<hipStream_t>(stream)>>>(x, reinterpret_cast<bf16_t*>(out_bf16), nwin, t, nblk);
     TUP_CHECK_LAUNCH();
     return 0;
 }

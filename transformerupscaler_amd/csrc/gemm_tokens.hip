@@ -1170,7 +1170,8 @@ extern "C" int tup_patch_embed_fwd(const void* feat, const void* Wt, const float
 
 // x: fp32 [B*nWy*nWx*64][192] window layout.  Wt: [4096][192] bf16, n = (i*8+j)*64 + o (rows permuted
 // per 64-group).  bias: [64].  skip / out: [B][H][W][64] bf16 NHWC; out = skip + unembed(x) + bias.
-extern "C" int tup_patch_unembed_fwd(const float* x, const void* Wt, const float* bias, const void* skip,
+// x_bf16 != 0: x is bf16 [..][192] (tup_blocks_stream_fwd's out_bf16) -- the same values the fp32 form is rounded to on load.
+extern "C" int tup_patch_unembed_fwd(const void* x, int x_bf16, const void* Wt, const float* bias, const void* skip,
                                      void* out, int B, int H, int W, void* stream)
 {
     GemmParams p{};
@@ -1179,6 +1180,7 @@ extern "C" int tup_patch_unembed_fwd(const float* x, const void* Wt, const float
     p.A = x; p.lda = 192; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.out = out; p.skip = (const bf16_t*)skip;
     p.M = B * p.nWy * p.nWx * 64; p.N = 4096; p.K = 192;
     static const bool use_panel = !TUP_ENV_FLAG("TUP_GEMM_NOPANEL");
+    if (x_bf16) return launch_panel<A_BF16, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     if (use_panel) return launch_panel<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
     return launch<A_F32, E_UNEMBED>(p, reinterpret_cast<hipStream_t>(stream));
 }

@@ -53,6 +53,8 @@ stream_blocks = True
 # the streamed kernel's workgroup carries four windows (one workgroup per CU): launches that would leave most CUs without one stay on the
 # 16x16x32 kernel, whose small-launch form runs one window per workgroup (the 720p -> 4K overlay frame: 240 windows; config 4: 540)
 STREAM_MIN_WINDOWS = 512
+# the streamed kernel hands its result to patch_unembed as bf16 tokens (the rounding that GEMM applies on load anyway; A/B attribute)
+stream_bf16_tokens = True
 fuse_blocks = True      # inference: fused MLP half (csrc/fused_blocks.hip); False = one kernel per op
 fuse_tail = True        # inference: fused output tail (csrc/tail_fused.hip)
 stream_tail = True     # A/B attribute; last stage x2: the register-streaming tail (csrc/tail_stream.hip) [+ separable Resize]
@@ -64,13 +66,15 @@ def _block_operands(pk, i, bias_frags):
             pk[f"b{i}.fc1.wfqn"], pk[f"b{i}.fc1.bqn"], pk[f"b{i}.fc2.wh4"], pk[f"b{i}.fc2.b"])
 
 
-def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None):
-    """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6."""
+def transformer_blocks(pk: Dict[str, torch.Tensor], x: torch.Tensor, bias_frags, capture=None, bf16_out: bool = False):
+    """x: fp32 [M][192] window layout, updated in place.  model.py:153-172 x6.
+    bf16_out (the caller feeds the result to patch_unembed, whose GEMM rounds its operand to bf16 anyway): the streamed kernel then
+    returns the tokens as a bf16 tensor (the same rounding, half the bytes to write and to read back); every other route ignores it."""
     if (fuse_blocks and fuse_attention >= 3 and capture is None and "b0.stream.0" in pk and blocks_in_one_launch and stream_blocks
             and x.shape[0] // 64 >= STREAM_MIN_WINDOWS):
         # all six blocks in ONE launch of the streamed kernel (csrc/block_stream.hip)
         table = ops.stream_table([tuple(pk[f"b{i}.stream.{j}"] for j in range(7)) for i in range(BLOCKS)])
-        return ops.blocks_stream(x, table)
+        return ops.blocks_stream(x, table, out_bf16=bf16_out and stream_bf16_tokens)
     if fuse_blocks and fuse_attention >= 3 and capture is None and "b0.proj.wpp" in pk and blocks_in_one_launch:
         # all six blocks in ONE launch (csrc/fused_attn.hip)
         table = ops.block_table([_block_operands(pk, i, bias_frags) for i in range(BLOCKS)])
@@ -151,7 +155,7 @@ def forward(pk: Dict[str, torch.Tensor], bias_frags, x: torch.Tensor, scale: int
     if cap is not None:
         cap["win_in"] = xw.clone()
     with _stage("blocks"):
-        xw = transformer_blocks(pk, xw, bias_frags, cap)
+        xw = transformer_blocks(pk, xw, bias_frags, cap, bf16_out=cap is None)
     with _stage("unembed"):
         combined = ops.patch_unembed(xw, pk["pu.w"], pk["pu.b"], feat)
     with _stage("dec1"):

@@ -413,13 +413,17 @@ def stream_table(blocks):
     return ((ctypes.c_void_p * len(ptrs))(*ptrs), len(blocks), [list(b) for b in blocks])
 
 
-def blocks_stream(x, table):
-    """In place: the table's consecutive WindowTransformerBlocks in one launch of the streamed 32x32x16 kernel (csrc/block_stream.hip)."""
+def blocks_stream(x, table, out_bf16=False):
+    """The table's consecutive WindowTransformerBlocks in one launch of the streamed 32x32x16 kernel (csrc/block_stream.hip).
+    out_bf16=False: in place, returns x.  out_bf16=True: returns the result as a NEW bf16 [M][192] tensor (round to nearest even of
+    the same values) and leaves x holding the kernel's parked intermediate -- for patch_unembed, whose GEMM rounds its operand to
+    bf16 anyway and then reads half the bytes."""
     M = x.shape[0]
     assert M % 64 == 0
     arr, nblk, _keep = table
-    _lib.call("tup_blocks_stream_fwd", _chk(x, F32, (M, 192), "x"), arr, nblk, M // 64, _stream())
-    return x
+    out = torch.empty((M, 192), dtype=BF16, device=x.device) if out_bf16 else None
+    _lib.call("tup_blocks_stream_fwd", _chk(x, F32, (M, 192), "x"), out.data_ptr() if out_bf16 else None, arr, nblk, M // 64, _stream())
+    return out if out_bf16 else x
 
 
 def fused_block(x, wh, bh, bias_frag, wproj, bproj, w1, b1, w2, b2):
@@ -467,7 +471,8 @@ def patch_unembed(x, wt, bias, skip):
     B, H, W, C = skip.shape
     _, _, nwy, nwx = window_geometry(H, W)
     out = torch.empty_like(skip)
-    _lib.call("tup_patch_unembed_fwd", _chk(x, F32, (B * nwy * nwx * 64, 192), "x"), _chk(wt, BF16, (4096, 192), "wt"),
+    x16 = x.dtype == BF16            # the streamed block kernel's bf16 output (ops.blocks_stream(out_bf16=True))
+    _lib.call("tup_patch_unembed_fwd", _chk(x, BF16 if x16 else F32, (B * nwy * nwx * 64, 192), "x"), int(x16), _chk(wt, BF16, (4096, 192), "wt"),
               _chk(bias, F32, (64,), "bias"), _chk(skip, BF16, None, "skip"), out.data_ptr(), B, H, W, _stream())
     return out
 

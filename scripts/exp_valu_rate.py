@@ -5,7 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = ctypes.CDLL(os.path.join(root, "transformerupscaler_amd", "libtupscale_valu_rate_exp.so"))
 P = ctypes.c_void_p
 lib.tup_exp_valu_rate.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
-names = ["v_fma_f32", "v_pk_fma_f16", "v_fma_f16", "v_pk_mul_f16", "v_cvt_pk_f16_f32", "v_exp_f32", "v_pk_max_f16", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_mul_f32", "s_nop 0", "s_add_u32", "ds_read_b128", "v_mov_b32", "v_fmac_f32", "v_pk_fmac_f16", "v_add_f32", "s_waitcnt (no wait)"]
+names = ["v_fma_f32", "v_pk_fma_f16", "v_fma_f16", "v_pk_mul_f16", "v_cvt_pk_f16_f32", "v_exp_f32", "v_pk_max_f16", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_mul_f32", "s_nop 0", "s_add_u32", "ds_read_b128", "v_mov_b32", "v_fmac_f32", "v_pk_fmac_f16", "v_add_f32", "s_waitcnt (no wait)", "v_pk_fma_f32", "v_pk_mul_f32", "v_fmac_f32 (sgpr src)"]
 out = torch.zeros(2048, dtype=torch.int64, device="cuda")
 reps = 256
 def run(kind, nf8, mf, waves):

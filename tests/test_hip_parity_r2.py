@@ -94,6 +94,14 @@ def test_config4_batch4_540p_x4(model, golden_dir):
                 assert torch.equal(yb[i:i + 1], model(x[i:i + 1], upscale_factor=4))
         finally:
             engine.STREAM_MIN_WINDOWS = keep
+        # the six blocks' launch handing patch_unembed bf16 tokens (the default) changes nothing: that GEMM rounds fp32 tokens to the
+        # same bf16 values on load
+        keep16 = engine.stream_bf16_tokens
+        engine.stream_bf16_tokens = False
+        try:
+            assert torch.equal(yb, model(x, upscale_factor=4))
+        finally:
+            engine.stream_bf16_tokens = keep16
 
 
 # ---------------------------------------------------------------- ΔPSNR <= 0.01 dB ----------------------------------------

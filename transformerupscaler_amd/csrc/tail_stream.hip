@@ -4,7 +4,8 @@
 //     out = clamp(sum, 0, 1) (optional)                                          model.py:327
 // RESIZE = true appends the antialiased Resize of model.py:323-325 (tap tables of at most 4 taps per axis, i.e. down-scaling by
 // up to 1.5) and the clamp: the pre-resize sums never leave the wave.  Vertically the last 6 HR rows of a lane's two columns sit in
-// a register ring and an output row is emitted as soon as its last input row exists; horizontally the vertically filtered row goes
+// a wave-private LDS ring (round 4: 36 registers less = three waves per SIMD instead of two; a lane reads back only what it wrote)
+// and an output row is emitted as soon as its last input row exists; horizontally the vertically filtered row goes
 // through a 1.5 KB wave-private LDS line from which every lane gathers the taps of its (up to two) output columns.
 //
 // Why not tiles: the tiled kernel (tail_fused.hip) walks the stencil chain through three LDS tiles with a barrier between stages; a
@@ -59,7 +60,7 @@ TUP_DEVICE float from_right(float v) {    // lane l <- lane l + 1 (0 into lane 6
 // (the pointers are separate __restrict__ parameters: the weight reads inside the row loop stay scalar loads only while hipcc can
 // prove that the kernel's own stores do not alias them)
 template <bool RESIZE>
-__global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
+__global__ __launch_bounds__(256, 3) void tail_stream_r2_kernel(
     const float* __restrict__ x_arg, const float* __restrict__ wfu_arg, const float* __restrict__ bfu_arg,
     const float* __restrict__ wfc_arg, const float* __restrict__ bfc_arg, const float* __restrict__ ui_arg, float* __restrict__ out_arg,
     const TailStreamParams p)
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     // kernel follows the copy.
     __shared__ __attribute__((aligned(16))) float wl[36 * 12 + 12 + 4];
     __shared__ __attribute__((aligned(16))) float hb[RESIZE ? 4 : 1][3][128];          // RESIZE: one vertically filtered HR line per wave
+    __shared__ __attribute__((aligned(16))) float xwl[RESIZE ? 4 : 1][2][64][4];       // RESIZE: the lanes' horizontal tap weights (per wave, pass, lane)
+    // RESIZE: the last six HR rows of the sums (slot = HR row % 6 = 2 (LR row % 3) + i), per wave, channel and lane -- in LDS, not in 36
+    // registers: a lane only ever reads what it wrote itself; an output row reads its (at most four) tap rows
+    __shared__ __attribute__((aligned(16))) f32x2 vrl[RESIZE ? 4 : 1][6][3][64];
     for (int i = threadIdx.x; i < 27 * 12; i += 256) wl[i] = wfu_arg[i];
     if (threadIdx.x < 27 * 4) wl[324 + threadIdx.x] = wfc_arg[threadIdx.x];
     if (threadIdx.x < 12) wl[432 + threadIdx.x] = bfu_arg[threadIdx.x];
@@ -108,19 +113,13 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
     f32x2 xn[3];                    // [0] = LR row r + 2 of channel c, requested at the top of iteration r
     f32x2 un[1][3][2];              // upscaled_input (HR rows 2q, 2q+1): requested at the end of iteration q (stage C of q - 1 has read the previous rows), used in q + 1
 
-    // RESIZE state: the last six HR rows of the sums (slot = HR row % 6 = 2 (LR row % 3) + i), the lane's output columns of the
-    // two gather passes with their first tap (as an index into the wave's LDS line) and weights, the band's next output row
-    f32x2 VR[RESIZE ? 6 : 1][3];
+    // RESIZE state: the lane's output columns of the two gather passes with their first tap (as an index into the wave's LDS line),
+    // the band's next output row (the last six HR rows of the sums and the lanes' tap weights live in LDS: vrl, xwl)
     int oxl[2] = {0, 0}, xi[2] = {0, 0};
     bool hval[2] = {false, false};
-    float xwt[2][4] = {};
     int oy = 0, oy_end = 0;
     const int wv = threadIdx.x >> 6;
     if constexpr (RESIZE) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) VR[k][c] = f32x2{0.f, 0.f};         // (an unwritten slot meets weight 0: it must not hold a NaN)
         const int ox0 = p.oxb[strip], ox1 = p.oxb[strip + 1];
         const int hx0 = 2 * (strip * p.sc - 2);                           // HR column of LDS index 0 (lane 0's first column)
 #pragma unroll
@@ -129,8 +128,12 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
             hval[q] = ox < ox1;
             oxl[q] = hval[q] ? ox : ox0;
             xi[q] = hval[q] ? p.xmin[oxl[q]] - hx0 : 4;
+            // (the four tap weights of the pass live in LDS, not in eight registers for the whole band: one ds_read_b128 per pass and
+            // output row; the kernel is bound by what a wave can issue, and 168 registers = a third wave per SIMD)
+            f32x4 wq4;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xwt[q][t] = (hval[q] && t < p.KX) ? p.xw[oxl[q] * p.KX + t] : 0.f;
+            for (int t = 0; t < 4; ++t) wq4[t] = (hval[q] && t < p.KX) ? p.xw[oxl[q] * p.KX + t] : 0.f;
+            *reinterpret_cast<f32x4*>(&xwl[wv][q][lane][0]) = wq4;
         }
         oy = p.oyb[band];
         oy_end = p.oyb[band + 1];
@@ -176,11 +179,16 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
         for (int j = 0; j < 3; ++j)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[g % 3][j]) : "v"(wbase), "i"((g * 12 + j * 4) * 4));
     };
+    // bfu (three reads at the top of stage B) and bfc (one read in front of the last group request of stage B: live for one group
+    // instead of for the whole stage)
     f32x4 bias[4];
     auto rd_bias = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 3; ++j)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[j]) : "v"(wbase), "i"((432 + j * 4) * 4));
+    };
+    auto rd_bias3 = [&]() __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bias[3]) : "v"(wbase), "i"((432 + 12) * 4));
     };
 
     // One LR row: stage B = T(r) from the LR rows r-1, r, r+1 (slots SM, S, SP), zero outside the image (the 3 -> 3 conv zero-pads
@@ -194,8 +202,7 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
         // RULE for the asynchronous reads: hipcc believes an asm output is written AT the asm statement.  An output that is never
         // used afterwards is dead to it from that point: the register goes to the next value computed, and the data lands on
         // top of that value later.  So every read's destination is "used" (really, or by an empty asm) BEHIND the wait that
-        // covers it.  bias[3] (bfc) is unused when stage C does not run:
-        asm volatile("" ::"v"(bias[3]));
+        // covers it.
         // explicit pairs (v_pk_fma_f32): left to the SLP vectoriser the scalar chains of ALL taps are gathered into one block of
         // packed FMAs behind the last read -- every weight group live at once, 280 spilled registers
         f32x2 acc[6];                   // pair j = outputs 2j, 2j+1 = (channel j >> 1, HR row j & 1), columns 2x, 2x+1
@@ -206,6 +213,8 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
         for (int g = 0; g < 27; ++g) {
             // (the groups of the 3 -> 3 conv are requested whether or not stage C runs: a conditional request costs hipcc's register
             //  allocation more than the six wasted reads of a band's first two rows)
+            // (request order at g = 26: groups 26 [being waited for], 27, bfc, 28 -- ten reads, the four oldest done = group 26)
+            if (g == 26) rd_bias3();
             rd(g + 2); lds_wait<6>();
             __builtin_amdgcn_sched_barrier(0);
             const float xo = X[slots[(g / 3) % 3]][g / 9];
@@ -227,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
             lds_wait<0>();
 #pragma unroll
             for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(ring[27 % 3][j]), "v"(ring[28 % 3][j]));      // groups 27, 28: see RULE
+            asm volatile("" ::"v"(bias[3]));                                                                 // ... and bfc
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool ok = colok && r >= 0 && r < H;
@@ -241,6 +251,8 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
             }
         if (!doC) return;
         const int q = r - 1;
+        lds_wait<3>();                  // outstanding: group 27, bfc, group 28 -> the first two have landed
+        __builtin_amdgcn_sched_barrier(0);
         f32x2 ac[2][3];                 // [HR row][channel] = columns 2x, 2x+1
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -289,34 +301,37 @@ __global__ __launch_bounds__(256, 2) void tail_stream_r2_kernel(
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int o = 0; o < 3; ++o) VR[2 * SM + i][o] = ac[i][o];
+                for (int o = 0; o < 3; ++o) vrl[wv][2 * SM + i][o][lane] = ac[i][o];
             while (oy < oy_end) {
                 const int ym = nym, yn = nyn;                          // this row's taps were fetched an emission ago (scalar loads:
                 if (ym + yn - 1 > 2 * q + 1) break;                    // their latency would otherwise sit in front of every row)
-                float ws[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // tap weights by ring slot (wave-uniform)
+                // the row's taps: ring slot (wave-uniform) and weight; a tap beyond the row's count reads the first tap's row with weight 0
+                // (an unwritten slot may hold anything)
+                int sl[4];
+                float wa[4];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const int sl = (ym + a) % 6;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) ws[k] = (sl == k && a < yn) ? nyw[a] : ws[k];
+                    sl[a] = a < yn ? (ym + a) % 6 : ym % 6;
+                    wa[a] = a < yn ? nyw[a] : 0.f;
                 }
                 fetch_row_taps(oy + 1);
                 f32x2 vr[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    vr[c] = f32x2{ws[0], ws[0]} * VR[0][c];
+                    vr[c] = f32x2{wa[0], wa[0]} * vrl[wv][sl[0]][c][lane];
 #pragma unroll
-                    for (int k = 1; k < 6; ++k) vr[c] = __builtin_elementwise_fma(f32x2{ws[k], ws[k]}, VR[k][c], vr[c]);
+                    for (int a = 1; a < 4; ++a) vr[c] = __builtin_elementwise_fma(f32x2{wa[a], wa[a]}, vrl[wv][sl[a]][c][lane], vr[c]);
                     *reinterpret_cast<f32x2*>(&hb[wv][c][2 * lane]) = vr[c];
                 }
 #pragma unroll
                 for (int pq = 0; pq < 2; ++pq)
                     if (hval[pq]) {
+                        const f32x4 xwt = *reinterpret_cast<const f32x4*>(&xwl[wv][pq][lane][0]);
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            float o = xwt[pq][0] * hb[wv][c][xi[pq]];
+                            float o = xwt[0] * hb[wv][c][xi[pq]];
 #pragma unroll
-                            for (int t = 1; t < 4; ++t) o = __builtin_fmaf(xwt[pq][t], hb[wv][c][xi[pq] + t], o);
+                            for (int t = 1; t < 4; ++t) o = __builtin_fmaf(xwt[t], hb[wv][c][xi[pq] + t], o);
                             if (p.clamp01) o = fminf(fmaxf(o, 0.f), 1.f);
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ro, (unsigned)oxl[pq] * 4u,
                                                                   (((b * 3 + c) * p.Ho + oy) * p.Wo) * 4, 0);

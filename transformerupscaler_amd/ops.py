@@ -199,6 +199,9 @@ def tail_fused(x, wfu, bfu, wfc, bfc, ui, r, out_hw, clamp=True):
     return out
 
 
+TAIL_STREAM_WAVES_PER_SIMD = 3      # csrc/tail_stream.hip: 150 registers, 52 KB of LDS per four-wave workgroup
+
+
 def _tail_stream_plan(device, B, H, W, Ho, Wo):
     """Decomposition of the fused streaming tail + Resize (csrc/tail_stream.hip, RESIZE = true): strip stride, band height, the
     output columns / rows each strip / band owns.  None when a tap table has more than 4 taps (then the Resize runs as its own kernel)."""
@@ -212,7 +215,7 @@ def _tail_stream_plan(device, B, H, W, Ho, Wo):
             sc = 60 - (int(xn.max()) - 1 + 1) // 2
             ext = (int(yn.max()) - 1 + 1) // 2
             nstrip = (W + sc - 1) // sc
-            nb = max(1, (256 * 4 * 2) // max(1, B * nstrip))            # fill the chip once at two waves per SIMD
+            nb = max(1, (256 * 4 * TAIL_STREAM_WAVES_PER_SIMD) // max(1, B * nstrip))      # fill the chip once at the kernel's occupancy
             bh = max(12, ((H + nb - 1) // nb + 2) // 3 * 3)
             nband = (H + bh - 1) // bh
             oxb = np.searchsorted(xlo, 2 * sc * np.arange(nstrip + 1), side="left").astype(np.int32)

@@ -15,3 +15,7 @@ def t(fn, n=10):
     return sorted(ts)[len(ts) // 2]
 us = t(lambda: ops.conv_c64_wgrad(x, g, 1))
 print("conv_c64_wgrad 4x720p: %.1f us (incl. two small zero fills)  %.0f TFLOP/s" % (us, 2 * B * H * W * 64 * 576 / us / 1e6))
+d = (torch.randn(B, H, W, 64, device="cuda") * 0.5).bfloat16()
+gp = torch.randn(B, 3, H, W, device="cuda") * 0.1
+us = t(lambda: ops.conv_thin_wgrad(d, gp, True))
+print("conv_thin_wgrad 4x720p: %.1f us  %.2f TB/s" % (us, (d.numel() * 2 + gp.numel() * 4) / us / 1e6))

@@ -25,6 +25,9 @@ GUARDED = [
     ("conv3x3_c64.hip", ["conv_c64_persistent_kernel", "bra_rows_persistent_kernel", "conv3_thin_rows_kernel"]),
     ("conv_thin.hip", ["conv3x3_c3_persistent_kernel"]),
     ("gemm_tokens.hip", ["gemm_panel2_kernel", "patch_embed_kernel"]),
+    # no counted hand-off here: guarded because the unrolled halo-row loops sit at 240 / 202 registers and a build that hoists their
+    # read addresses out of the tile loop spills (seen twice while they were written)
+    ("conv_bwd.hip", ["conv3x3_wgrad_c64_kernel", "conv3x3_wgrad_thin_kernel"]),
 ]
 # diagnostic template instantiations, never launched by the product path: fused_qkv_attn_kernel<PROJ, MLP, STAMPS = true>, the
 # timing ablations fused_mlp_v2_kernel<ABL != 0>

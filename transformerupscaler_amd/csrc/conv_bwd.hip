@@ -65,6 +65,10 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c64_kernel(
     constexpr int XP = (NPIX_HALO * 8 + 511) / 512;
     u32x4 xpre[XP], gpre[4];
     const int xsi = xsp / xr, xsj = xsp % xr;
+    // A piece's offset from its tile's first halo pixel does not depend on the tile (xrel / grel, set once): an interior tile costs
+    // one 64-bit add per load; the general form (clipping at the map's edges) is ~28 vector instructions per load and was a third
+    // of the kernel's vector work.
+    const bool last_ok = tid + (XP - 1) * 512 < NPIX_HALO * 8;
     auto fetch_tile = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
@@ -72,6 +76,26 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c64_kernel(
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
         const bf16_t* xb = x + (size_t)b * H * W * 64 * xr * xr;
+        const bf16_t* gb0 = gmap + (size_t)b * Hg * Wg * 64;
+        if (ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + TW + 1 <= W) {          // interior tile
+            const bf16_t* xt = xb + ((size_t)((ty0 - 1) * xr + xsi) * (W * xr) + ((tx0 - 1) * xr + xsj)) * 64;
+            const bf16_t* gt = gb0 + ((size_t)(ty0 * gr + si) * Wg + (tx0 * gr + sj)) * 64;
+            // (rebuilt from the thread index per tile -- six instructions per load; as loop invariants the ten offsets cost the
+            // K loop its registers: 256 + scratch)
+            const int tq = (int)opaque_copy((uint32_t)tid);
+#pragma unroll
+            for (int u = 0; u < XP; ++u) {
+                const int idx = min(tq + u * 512, NPIX_HALO * 8 - 1);
+                const int q = idx >> 3, c = idx & 7;
+                const int yy = (q * 241) >> 13, xx = q - yy * HALO_W;            // q / 34 for q < 340
+                xpre[u] = u32x4{0u, 0u, 0u, 0u};
+                if (u + 1 < XP || last_ok) xpre[u] = *reinterpret_cast<const u32x4*>(xt + ((yy * xr) * (W * xr) + xx * xr) * 64 + c * 8);
+            }
+            const bf16_t* gl = gt + (((tq >> 8) * gr) * Wg + ((tq >> 3) & 31) * gr) * 64 + (tq & 7) * 8;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) gpre[u] = *reinterpret_cast<const u32x4*>(gl + (size_t)u * (2 * gr * Wg * 64));
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int idx = tid + u * 512;
@@ -106,6 +130,26 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c64_kernel(
         }
     };
 
+    // lane constants of the fragment reads (see the K loop): G rows are 32 pixels, so their swizzle phase does not depend on the row
+    int gbase[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int gcol = 16 * (2 * coh + c) + 4 * trp;
+            gbase[c][h] = swz128(8 * g + trq + 4 * h, gcol >> 3) + (gcol & 7) * 2;
+        }
+    // X: pixel q = hy * 34 + 8g + trq + dx + 4h, logical chunk xc, byte (xcol & 7) * 2 inside it
+    const int xcol = 16 * cit + 4 * trp, xc = xcol >> 3;
+    int xs[3][2], xb0[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q0 = 8 * g + trq + dx + 4 * h;
+            xs[dx][h] = q0 >> 1;
+            xb0[dx][h] = q0 * 128 + (xcol & 7) * 2;
+        }
     const int ntiles = tilesX * tilesY * B;
     if ((int)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -114,35 +158,54 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c64_kernel(
         if (tile + (int)gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
         // One K-step = one tile row of 32 pixels on v_mfma_f32_16x16x32_bf16 (the 16x16x16 form runs at half its
         // rate on gfx950): lane group g contracts pixels 8g .. 8g+7, delivered by two transposed reads (4 pixels each).
+        // The loop runs over the ten HALO rows: the three dx fragments of halo row hy serve the taps (dy, dx) of output rows
+        // hy - dy, so every X fragment is read once per tile (30 instead of 72) against a window of three rows' G fragments.
+        // Addresses: the swizzle phase of pixel q is (q >> 1) & 7 and a halo row is 34 pixels = 17 pairs, so row hy shifts the
+        // phase of row 0 by hy; what is left per read is add / and / xor / shift-add on a lane constant, the row's byte offset
+        // is an immediate.  (The row loop used to rebuild every address from q: 926 vector instructions per tile and wave for
+        // 144 MFMAs -- the kernel ran on the vector port, profiles/r04_pmc_mfma_train.json: 5.4 per MFMA, matrix pipe 30 % busy.)
         auto join = [](s16x4 lo, s16x4 hi) {
             const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
             return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
         };
-#pragma unroll 1
-        for (int ry = 0; ry < TH; ++ry) {
-            const int gp = ry * 32 + 8 * g + trq;
-            bf16x8 af[2];
+        bf16x8 gf[3][2];                 // G fragments of output rows hy, hy - 1, hy - 2 (slot = row % 3)
+        // the phases pass through an empty asm per tile: left visible, hipcc hoists all 60 read addresses out of the tile loop
+        // (256 registers + scratch)
+        uint32_t xst[3][2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int gcol = 16 * (2 * coh + c) + 4 * trp;
-                af[c] = join(lds_read_tr16(g_lds + swz128(gp, gcol >> 3) + (gcol & 7) * 2),
-                             lds_read_tr16(g_lds + swz128(gp + 4, gcol >> 3) + (gcol & 7) * 2));
-            }
-            if (cit == 0) {    // bias gradient: this lane holds G[8 pixels][co = 16*(2*coh + c) + l16]
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xst[dx][h] = opaque_copy((uint32_t)xs[dx][h]);
+#pragma unroll
+        for (int hy = 0; hy < HALO_H; ++hy) {
+            if (hy < TH) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
+                    gf[hy % 3][c] = join(lds_read_tr16(g_lds + gbase[c][0] + hy * 4096), lds_read_tr16(g_lds + gbase[c][1] + hy * 4096));
+                if (cit == 0) {    // bias gradient: this lane holds G[8 pixels][co = 16*(2*coh + c) + l16]
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bsum[c] += bf16_to_f32(af[c][j]);
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bsum[c] += bf16_to_f32(gf[hy % 3][c][j]);
+                }
             }
-            const int qbase = ry * HALO_W + 8 * g + trq;
-            const int xcol = 16 * cit + 4 * trp;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int q = qbase + (tap / 3) * HALO_W + (tap % 3);
-                const bf16x8 bfr = join(lds_read_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2),
-                                        lds_read_tr16(x_lds + swz128(q + 4, xcol >> 3) + (xcol & 7) * 2));
+            for (int dx = 0; dx < 3; ++dx) {
+                s16x4 part[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[tap][c] = mfma16x16x32(af[c], bfr, acc[tap][c]);
+                for (int h = 0; h < 2; ++h) {
+                    const int ph = (int)((xst[dx][h] + hy) & 7u);
+                    part[h] = lds_read_tr16(x_lds + xb0[dx][h] + ((xc ^ ph) << 4) + hy * (HALO_W * 128));
+                }
+                const bf16x8 bfr = join(part[0], part[1]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int ry = hy - dy;
+                    if (ry >= 0 && ry < TH) {
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[dy * 3 + dx][c] = mfma16x16x32(gf[ry % 3][c], bfr, acc[dy * 3 + dx][c]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -172,8 +235,11 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_c64_kernel(
 
 // ------------------------------------------------------------------------------------------------
 // thin convs (cout = 3: up1_conv, decoder_conv2): G planar fp32 [B][3][H][W], X NHWC bf16.
-// dwp[co][tap][ci] += ..., dbias[co] += sum G.  Same MFMA scheme as the 64-cout kernel with the 3 real
-// couts padded to one 16-row tile; the four waves split the 9 taps instead of the cout tiles.
+// dwp[co][tap][ci] += ..., dbias[co] += sum G.  The 64-cout kernel's scheme with the 3 real couts padded to one 16-row tile:
+// wave = input-channel tile, all nine taps, one K-step per tile row on v_mfma_f32_16x16x32_bf16, the loop over the ten halo
+// rows (each X fragment read once, a window of three rows' G fragments), read addresses from lane constants.  (Until round 4
+// the four waves split the taps on the 16x16x16 form and rebuilt every swizzled address from the pixel index: 740 vector
+// instructions per tile and wave for 144 half-rate MFMAs, 2.0 TB/s.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
     const bf16_t* __restrict__ x, const float* __restrict__ gpl, float* __restrict__ dwp, float* __restrict__ dbias,
@@ -182,15 +248,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* x_lds = smem;
     bf16_t* g_lds = reinterpret_cast<bf16_t*>(smem + X_TILE_BYTES);     // [256 pixels][16 couts] (3 real)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, cit = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
     const int trq = l16 >> 2, trp = l16 & 3;
-    const int ntap = (wave == 0) ? 3 : 2;                  // taps {0,4,8}, {1,5}, {2,6}, {3,7}
-    f32x4 acc[3][4];
+    f32x4 acc[9];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum[3] = {0.f, 0.f, 0.f};
     for (int i = tid; i < 256 * 16; i += 256) g_lds[i] = f32_to_bf16(0.f);       // columns 3..15 stay zero
     // register double-buffering of the tile operands (X halo: 11 pieces per thread, G: this thread's pixel): the loads
@@ -198,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
     constexpr int XP = (NPIX_HALO * 8 + 255) / 256;
     u32x4 xpre[XP];
     float gpre[3];
+    const bool last_ok = tid + (XP - 1) * 256 < NPIX_HALO * 8;
     auto fetch_tile = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
@@ -205,6 +269,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
         const int b = t / tilesY;
         const int ty0 = ty * TH, tx0 = tx * TW;
         const bf16_t* xb = x + (size_t)b * H * W * 64;
+        if (ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + TW + 1 <= W) {          // interior tile: offsets from the thread index
+            const bf16_t* xt = xb + ((size_t)(ty0 - 1) * W + (tx0 - 1)) * 64;
+            const int tq = (int)opaque_copy((uint32_t)tid);                             // (not hoisted: see the 64-cout kernel)
+#pragma unroll
+            for (int u = 0; u < XP; ++u) {
+                const int idx = min(tq + u * 256, NPIX_HALO * 8 - 1);
+                const int q = idx >> 3, c = idx & 7;
+                const int yy = (q * 241) >> 13, xx = q - yy * HALO_W;                   // q / 34 for q < 340
+                xpre[u] = u32x4{0u, 0u, 0u, 0u};
+                if (u + 1 < XP || last_ok) xpre[u] = *reinterpret_cast<const u32x4*>(xt + (yy * W + xx) * 64 + c * 8);
+            }
+            const float* gp0 = gpl + ((size_t)b * 3 * H + ty0 + (tq >> 5)) * W + tx0 + (tq & 31);
+#pragma unroll
+            for (int co = 0; co < 3; ++co) gpre[co] = gp0[(size_t)co * H * W];
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int idx = tid + u * 256;
@@ -219,6 +299,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
         const bool ok = oy < H && ox < W;
 #pragma unroll
         for (int co = 0; co < 3; ++co) gpre[co] = ok ? gpl[(((size_t)b * 3 + co) * H + oy) * W + ox] : 0.f;
+    };
+    // lane constants of the fragment reads.  G rows are 32 bytes (16 couts), not swizzled: pixel ry * 32 + 8g + trq (+ 4)
+    const int gb0 = (8 * g + trq) * 32 + trp * 8;
+    // X: pixel q = hy * 34 + 8g + trq + dx + 4h; the swizzle phase of row hy is row 0's + hy (34 pixels = 17 pairs)
+    const int xcol = 16 * cit + 4 * trp, xc = xcol >> 3;
+    int xs[3][2], xb0[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q0 = 8 * g + trq + dx + 4 * h;
+            xs[dx][h] = q0 >> 1;
+            xb0[dx][h] = q0 * 128 + (xcol & 7) * 2;
+        }
+    auto join = [](s16x4 lo, s16x4 hi) {
+        const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+        return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
     };
     const int ntiles = tilesX * tilesY * B;
     if ((int)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
@@ -235,23 +332,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
         }
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
-#pragma unroll 1
-        for (int ks = 0; ks < 16; ++ks) {
-            const int ry = ks >> 1, x0 = (ks & 1) * 16;
-            const int gp = ry * 32 + x0 + 4 * g + trq;
-            const s16x4 af = lds_read_tr16(reinterpret_cast<const char*>(g_lds) + gp * 32 + trp * 8);
-            const int qbase = ry * HALO_W + x0 + 4 * g + trq;
+        uint32_t xst[3][2];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                if (a < ntap) {
-                    const int tap = wave + 4 * a;
-                    const int q = qbase + (tap / 3) * HALO_W + (tap % 3);
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                    for (int cit = 0; cit < 4; ++cit) {
-                        const int xcol = 16 * cit + 4 * trp;
-                        const s16x4 bfr = lds_read_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2);
-                        acc[a][cit] = mfma16x16x16(af, bfr, acc[a][cit]);
-                    }
+            for (int h = 0; h < 2; ++h) xst[dx][h] = opaque_copy((uint32_t)xs[dx][h]);
+        bf16x8 gf[3];                    // G fragments of output rows hy, hy - 1, hy - 2 (slot = row % 3)
+#pragma unroll
+        for (int hy = 0; hy < HALO_H; ++hy) {
+            if (hy < TH)
+                gf[hy % 3] = join(lds_read_tr16(reinterpret_cast<const char*>(g_lds) + gb0 + hy * 1024),
+                                  lds_read_tr16(reinterpret_cast<const char*>(g_lds) + gb0 + 128 + hy * 1024));
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                s16x4 part[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ph = (int)((xst[dx][h] + hy) & 7u);
+                    part[h] = lds_read_tr16(x_lds + xb0[dx][h] + ((xc ^ ph) << 4) + hy * (HALO_W * 128));
+                }
+                const bf16x8 bfr = join(part[0], part[1]);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int ry = hy - dy;
+                    if (ry >= 0 && ry < TH) acc[dy * 3 + dx] = mfma16x16x32(gf[ry % 3], bfr, acc[dy * 3 + dx]);
                 }
             }
         }
@@ -260,13 +364,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_thin_kernel(
     // D[row = co 4g+e][col = ci l16]: only rows 0..2 (g == 0, e < 3) are real
     if (g == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-            if (a < ntap)
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int cit = 0; cit < 4; ++cit)
-#pragma unroll
-                    for (int e = 0; e < 3; ++e)
-                        atomicAdd(dwp + ((size_t)e * 9 + wave + 4 * a) * 64 + 16 * cit + l16, acc[a][cit][e]);
+            for (int e = 0; e < 3; ++e) atomicAdd(dwp + ((size_t)e * 9 + tap) * 64 + 16 * cit + l16, acc[tap][e]);
     }
     if (dbias) {
 #pragma unroll
@@ -831,7 +931,8 @@ static int conv_c64_wgrad_launch(const void* x, const void* gmap, float* dwp, fl
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const size_t lds = X_TILE_BYTES + 256 * 128;
     TUP_SET_DYN_LDS((conv3x3_wgrad_c64_kernel), lds);
-    conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, 1)), dim3(512), lds, reinterpret_cast<hipStream_t>(stream)>>>(
+    static const int wg_per_cu = TUP_ENV_INT("TUP_WGRAD64_WG_PER_CU", 1);            // tuning knob (diagnostic build)
+    conv3x3_wgrad_c64_kernel<<<dim3(persistent_grid(nt, wg_per_cu)), dim3(512), lds, reinterpret_cast<hipStream_t>(stream)>>>(
         (const bf16_t*)x, (const bf16_t*)gmap, dwp, dbias, B, H, W, gr, sp, tilesX, tilesY, xr, xsp);
     TUP_CHECK_LAUNCH();
     return 0;
@@ -862,7 +963,8 @@ extern "C" int tup_conv3x3_thin_wgrad(const void* x, const float* gpl, float* dw
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long nt = (long long)tilesX * tilesY * B;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    conv3x3_wgrad_thin_kernel<<<dim3(persistent_grid(nt, 2)), dim3(256), X_TILE_BYTES + 256 * 32,
+    static const int thin_per_cu = TUP_ENV_INT("TUP_WGRADTHIN_WG_PER_CU", 2);        // tuning knob (diagnostic build)
+    conv3x3_wgrad_thin_kernel<<<dim3(persistent_grid(nt, thin_per_cu)), dim3(256), X_TILE_BYTES + 256 * 32,
                                 reinterpret_cast<hipStream_t>(stream)>>>((const bf16_t*)x, gpl, dwp, dbias, B, H, W, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     return 0;

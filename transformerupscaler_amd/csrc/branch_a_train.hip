@@ -12,6 +12,7 @@
 // packing.compose_branch_a); ring pixels are excluded from the main kernels and handled by the two small ring kernels.
 // Layouts: Wc [9 variants][12 n = c*4 + si*2 + sj][25 t = ty*5 + tx][64 ci]; feat / d feat NHWC bf16; g fp32 planar [B][3][2H][2W].
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -258,8 +259,13 @@ __global__ __launch_bounds__(256) void bra_dgrad_ring_kernel(const float* __rest
 }
 
 // ---- weight gradient, main part: G0[n][t][ci] += sum_px g12[px][n] feat[px + (ty-2, tx-2)][ci] (ring pixels are zero in g12).
-// MFMA 16x16x16 with both operands transposed out of LDS (pixels are the contraction), as conv3x3_wgrad_thin_kernel; the four
-// waves split the 25 taps, the partial sums live in registers across the persistent tile loop. ----
+// MFMA 16x16x32 with both operands transposed out of LDS (pixels are the contraction; one K-step = one tile row of 32 pixels),
+// the scheme of conv3x3_wgrad_thin_kernel (conv_bwd.hip): wave = input-channel tile with all 25 taps in registers across the
+// persistent tile loop; the loop runs over the twelve HALO rows -- the five dx fragments of halo row hy serve the taps (dy, dx) of
+// output rows hy - dy against a window of five rows' g fragments, so every x fragment is read once per tile (60 instead of 200) --
+// and the swizzled read addresses come from lane constants (a halo row is 36 pixels = 18 pairs: row hy shifts the phase by 2 hy).
+// (Until round 4: the four waves split the taps on the 16x16x16 form and rebuilt every address from the pixel index: 400 MFMAs,
+// 416 transposed reads and ~1,800 vector instructions per tile and wave, 365-379 us at 4 x 720p.) ----
 constexpr int WTH = 8, WTW = 32, WHW = WTW + 4, WHH = WTH + 4, WNPIX = WHH * WHW;          // 432
 constexpr int WX_BYTES = WNPIX * 128;                                                     // 55,296
 constexpr int WGRAD_LDS = WX_BYTES + 256 * 32;
@@ -268,89 +274,130 @@ TUP_DEVICE s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-__global__ __launch_bounds__(256, 2) void bra_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g12,
+__global__ __launch_bounds__(512, 1) void bra_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g12,
                                                            float* __restrict__ G0, int B, int H, int W, int tilesX, int tilesY)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* x_lds = smem;
     char* g_lds = smem + WX_BYTES;                              // [256 pixels][16 n] bf16
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // eight waves: input-channel tile cit = wave & 3, tap rows dy 0..2 (waves 0-3) or 3..4 (waves 4-7; one wave of each per SIMD).
+    // (Four waves with all 25 taps each: 100 accumulator + 56 staging registers, hipcc spills 176-376 B per lane.)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cit = wave & 3;
+    const int half = __builtin_amdgcn_readfirstlane(wave >> 2);
     const int g = lane >> 4, l16 = lane & 15;
     const int trq = l16 >> 2, trp = l16 & 3;
-    const int ntap = (wave == 0) ? 7 : 6;                       // taps wave, wave + 4, ...
-    f32x4 acc[7][4];
+    f32x4 acc[15];
 #pragma unroll
-    for (int a = 0; a < 7; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int XP = (WNPIX * 8 + 255) / 256;                 // 14
-    u32x4 xpre[XP], gpre[2];
+    for (int t = 0; t < 15; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int XP = (WNPIX * 8 + 511) / 512;                 // 7
+    u32x4 xpre[XP], gpre;
     const int ntiles = tilesX * tilesY * B;
+    const bool last_ok = tid + (XP - 1) * 512 < WNPIX * 8;
     auto fetch = [&](int tile) {
         int t = tile;
         const int tx = t % tilesX; t /= tilesX;
         const int ty = t % tilesY, b = t / tilesY;
         const bf16_t* xb = x + (size_t)b * H * W * 64;
+        const int ty0 = ty * WTH, tx0 = tx * WTW;
+        if (ty0 >= 2 && ty0 + WTH + 2 <= H && tx0 >= 2 && tx0 + WTW + 2 <= W) {        // interior tile: offsets from the thread index
+            const bf16_t* xt = xb + ((size_t)(ty0 - 2) * W + (tx0 - 2)) * 64;
+            const int tq = (int)opaque_copy((uint32_t)tid);                             // (not hoisted: the offsets would cost the K loop its registers)
+#pragma unroll
+            for (int u = 0; u < XP; ++u) {
+                const int idx = min(tq + u * 512, WNPIX * 8 - 1);
+                const int q = idx >> 3, c = idx & 7;
+                const int yy = (q * 911) >> 15, xx = q - yy * WHW;                      // q / 36 for q < 432
+                xpre[u] = u32x4{0u, 0u, 0u, 0u};
+                if (u + 1 < XP || last_ok) xpre[u] = *reinterpret_cast<const u32x4*>(xt + (yy * W + xx) * 64 + c * 8);
+            }
+            // g tile: 256 pixels x 32 B = 512 pieces of 16 B, one per thread
+            gpre = *reinterpret_cast<const u32x4*>(g12 + (((size_t)b * H + ty0 + (tq >> 6)) * W + tx0 + ((tq >> 1) & 31)) * 16 + (tq & 1) * 8);
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
-            const int idx = tid + u * 256, q = idx >> 3, c = idx & 7;
+            const int idx = tid + u * 512, q = idx >> 3, c = idx & 7;
             const int yy = q / WHW, xx = q - yy * WHW;
-            const int iy = ty * WTH - 2 + yy, ix = tx * WTW - 2 + xx;
+            const int iy = ty0 - 2 + yy, ix = tx0 - 2 + xx;
             xpre[u] = u32x4{0u, 0u, 0u, 0u};
             if (idx < WNPIX * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)
                 xpre[u] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * W + ix) * 64 + c * 8);
         }
-        const int oy = ty * WTH + (tid >> 5), ox = tx * WTW + (tid & 31);
-        gpre[0] = gpre[1] = u32x4{0u, 0u, 0u, 0u};
-        if (oy < H && ox < W) {
-            const u32x4* gp = reinterpret_cast<const u32x4*>(g12 + (((size_t)b * H + oy) * W + ox) * 16);
-            gpre[0] = gp[0]; gpre[1] = gp[1];
+        const int oy = ty0 + (tid >> 6), ox = tx0 + ((tid >> 1) & 31);
+        gpre = u32x4{0u, 0u, 0u, 0u};
+        if (oy < H && ox < W) gpre = *reinterpret_cast<const u32x4*>(g12 + (((size_t)b * H + oy) * W + ox) * 16 + (tid & 1) * 8);
+    };
+    // lane constants of the fragment reads.  g rows are 32 bytes (16 n), not swizzled: pixel ry * 32 + 8g + trq (+ 4)
+    const int gb0 = (8 * g + trq) * 32 + trp * 8;
+    // x: pixel q = hy * 36 + 8g + trq + dx + 4h, logical chunk xc, byte (xcol & 7) * 2 inside it
+    const int xcol = 16 * cit + 4 * trp, xc = xcol >> 3;
+    int xs[5][2], xb0[5][2];
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q0 = 8 * g + trq + dx + 4 * h;
+            xs[dx][h] = q0 >> 1;
+            xb0[dx][h] = q0 * 128 + (xcol & 7) * 2;
         }
+    auto join = [](s16x4 lo, s16x4 hi) {
+        const u32x2 a = __builtin_bit_cast(u32x2, lo), b = __builtin_bit_cast(u32x2, hi);
+        return __builtin_bit_cast(bf16x8, u32x4{a[0], a[1], b[0], b[1]});
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
-            const int idx = tid + u * 256;
+            const int idx = tid + u * 512;
             if (idx < WNPIX * 8) *reinterpret_cast<u32x4*>(x_lds + swz128(idx >> 3, idx & 7)) = xpre[u];
         }
-        reinterpret_cast<u32x4*>(g_lds + tid * 32)[0] = gpre[0];
-        reinterpret_cast<u32x4*>(g_lds + tid * 32)[1] = gpre[1];
+        reinterpret_cast<u32x4*>(g_lds)[tid] = gpre;
         __syncthreads();
         if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-#pragma unroll 1
-        for (int ks = 0; ks < 16; ++ks) {
-            const int ry = ks >> 1, x0 = (ks & 1) * 16;
-            const int gp = ry * 32 + x0 + 4 * g + trq;                      // pixel rows of the transposed read
-            const s16x4 af = lds_tr16(g_lds + gp * 32 + trp * 8);           // A[n = l16][k = pixel 4g + j]
-            const int qbase = (ry + 0) * WHW + x0 + 4 * g + trq;            // + (ty, tx) of the tap; halo origin (-2, -2)
+        uint32_t xst[5][2];              // through an empty asm per tile: left visible, hipcc hoists the read addresses out of the tile loop
 #pragma unroll
-            for (int a = 0; a < 7; ++a) {
-                if (a < ntap) {
-                    const int tap = wave + 4 * a;
-                    const int q = qbase + (tap / 5) * WHW + (tap % 5);
+        for (int dx = 0; dx < 5; ++dx)
 #pragma unroll
-                    for (int cit = 0; cit < 4; ++cit) {
-                        const int xcol = 16 * cit + 4 * trp;
-                        const s16x4 bfr = lds_tr16(x_lds + swz128(q, xcol >> 3) + (xcol & 7) * 2);
-                        acc[a][cit] = mfma16x16x16(af, bfr, acc[a][cit]);
+            for (int h = 0; h < 2; ++h) xst[dx][h] = opaque_copy((uint32_t)xs[dx][h]);
+        // tap rows DY0 .. DY0 + NDY - 1: halo rows DY0 .. DY0 + NDY + 6; output row ry pairs with halo row ry + dy
+        auto taps = [&](auto dy0c, auto ndyc) {
+            constexpr int DY0 = decltype(dy0c)::value, NDY = decltype(ndyc)::value;
+            bf16x8 gf[NDY];              // g fragments of output rows (hy - DY0) .. (hy - DY0 - NDY + 1), slot = row % NDY: A[n = l16][k = pixel 8g + j]
+#pragma unroll
+            for (int hy = DY0; hy < DY0 + NDY + WTH - 1; ++hy) {
+                const int rn = hy - DY0;
+                if (rn < WTH) gf[rn % NDY] = join(lds_tr16(g_lds + gb0 + rn * 1024), lds_tr16(g_lds + gb0 + 128 + rn * 1024));
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) {
+                    s16x4 part[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ph = (int)((opaque_copy(xst[dx][h]) + 2 * hy) & 7u);          // (opaque per row: the addresses stay in their row)
+                        part[h] = lds_tr16(x_lds + xb0[dx][h] + ((xc ^ ph) << 4) + hy * (WHW * 128));
+                    }
+                    const bf16x8 bfr = join(part[0], part[1]);
+#pragma unroll
+                    for (int d = 0; d < NDY; ++d) {
+                        const int ry = hy - DY0 - d;
+                        if (ry >= 0 && ry < WTH) acc[d * 5 + dx] = mfma16x16x32(gf[ry % NDY], bfr, acc[d * 5 + dx]);
                     }
                 }
+                asm volatile("" ::: "memory");          // a halo row at a time: left free, hipcc requests every row's fragments up front and spills
             }
-        }
+        };
+        if (half == 0) taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+        else taps(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
     }
     // D[row = n 4g+e][col = ci l16]; rows 12..15 are padding
     if (g < 3) {
+        const int ntl = half == 0 ? 15 : 10, tap0 = half == 0 ? 0 : 15;
 #pragma unroll
-        for (int a = 0; a < 7; ++a)
-            if (a < ntap)
+        for (int t = 0; t < 15; ++t)
+            if (t < ntl)
 #pragma unroll
-                for (int cit = 0; cit < 4; ++cit)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        // (9.8 M float atomics per launch; without them the kernel takes the same 362 us: not its bound)
-                        atomicAdd(G0 + (size_t)(blockIdx.x % REP) * GSZ + ((size_t)(4 * g + e) * NTAP + wave + 4 * a) * 64 + 16 * cit + l16, acc[a][cit][e]);
+                for (int e = 0; e < 4; ++e)
+                    atomicAdd(G0 + (size_t)(blockIdx.x % REP) * GSZ + ((size_t)(4 * g + e) * NTAP + tap0 + t) * 64 + 16 * cit + l16, acc[t][e]);
     }
 }
 
@@ -563,7 +610,7 @@ extern "C" int tup_bra_backward(const float* g, const float* ui, const void* fea
     bra_dgrad_ring_kernel<<<dim3((unsigned)((nframe + 3) / 4)), dim3(256), 0, s>>>(g, ui, (const bf16_t*)wv, (bf16_t*)dfeat, B, H, W);
     TUP_CHECK_LAUNCH();
     TUP_SET_DYN_LDS((bra_wgrad_kernel), WGRAD_LDS);
-    bra_wgrad_kernel<<<dim3(persistent_blocks(nt)), dim3(256), WGRAD_LDS, s>>>((const bf16_t*)feat, (const bf16_t*)g12, G, B, H, W, tilesX, tilesY);
+    bra_wgrad_kernel<<<dim3((unsigned)(nt < 256 ? nt : 256)), dim3(512), WGRAD_LDS, s>>>((const bf16_t*)feat, (const bf16_t*)g12, G, B, H, W, tilesX, tilesY);
     TUP_CHECK_LAUNCH();
     const long long nring = (long long)B * (4LL * W + 2LL * (2 * H - 2));
     if (nring > 0x7fffffffLL) return (int)hipErrorInvalidValue;

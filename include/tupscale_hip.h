@@ -209,6 +209,10 @@ int tup_gemm_wgrad_bias(const void* P, int p_dtype, int ldp, const void* Q, int 
 /* Weight gradient of patch_embed (reflect=1: P = grad tokens, map = feat) and of patch_unembed
  * (reflect=0: P = tokens, map = grad of its output).  out fp32 [192][4096] +=, column (i*8+j)*64+c. */
 int tup_patch_wgrad(const float* P, const void* map, float* out, int B, int H, int W, int reflect, void* stream);
+/* The same from bf16 token rows P [M][192] (the rounding tup_patch_wgrad applies on load, done by the caller) on the wide-tile
+ * kernel: one workgroup per CU owns 192 x 128 of the output, both operands by LDS-DMA, the map is read once instead of three
+ * times and the token rows 32 instead of 64 times.  B * H * W * 128 < 2^31. */
+int tup_patch_wgrad_bf16(const void* P, const void* map, float* out, int B, int H, int W, int reflect, void* stream);
 
 /* Bias gradients: out[N] += column sums of G [M][N] (dtype 0 bf16 / 1 fp32) over the rows with
  * rowmask[m] != 0 (uint8 [M]; NULL = all rows). */

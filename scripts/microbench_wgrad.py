@@ -17,3 +17,13 @@ for NI, NJ in ((576, 192), (192, 192), (768, 192), (192, 768)):
     out = torch.zeros(NI, NJ, device="cuda")
     us = t(lambda: ops.gemm_wgrad(p, q, out=out))
     print("NI %4d NJ %4d: %.1f us  %.0f TFLOP/s  %.2f TB/s (operands once)" % (NI, NJ, us, 2 * M * NI * NJ / us / 1e6, (p.numel() + q.numel()) * 2 / us / 1e6))
+
+# the two patch weights (192 x 4096, M = every token of 4 x 720p): the wide-tile kernel against the 64 x 64-tile one
+B, H, W = 4, 720, 1280
+fmap = (torch.randn(B, H, W, 64, device="cuda") * 0.5).to(torch.bfloat16)
+p = torch.randn(B * 12 * 20 * 64, 192, device="cuda")
+for wide in (True, False, True, False):
+    ops.PATCH_WGRAD_WIDE = wide
+    us = t(lambda: ops.patch_wgrad(p, fmap, True), n=10)
+    print("patch_wgrad (incl. the zero fill%s): %s %.1f us" % (" and the bf16 cast" if wide else "", "wide" if wide else "64x64", us))
+ops.PATCH_WGRAD_WIDE = True

@@ -283,6 +283,13 @@ def test_patch_embed_unembed_bwd(dev, hw):
     nhwc = feat.detach().permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
     dw = ops.patch_wgrad(gx.to(dev), nhwc, reflect=True).cpu().view(192, 8, 8, 64).permute(0, 3, 1, 2)
     close(dw, w.grad, 3e-2, 2e-2, "patch_embed dW")
+    # the wide-tile kernel (default) against the 64 x 64-tile one: same bf16 operands, fp32 sums in another order
+    ops.PATCH_WGRAD_WIDE = False
+    try:
+        dw_narrow = ops.patch_wgrad(gx.to(dev), nhwc, reflect=True).cpu().view(192, 8, 8, 64).permute(0, 3, 1, 2)
+    finally:
+        ops.PATCH_WGRAD_WIDE = True
+    close(dw, dw_narrow, 2e-3, 1e-4, "patch_embed dW, wide vs 64x64 tiles")
 
     # ---- patch_unembed backward: d tokens and d weight ----
     wu = bf(rnd((192, 64, 8, 8), 45, 0.05)).requires_grad_(True)

@@ -11,7 +11,7 @@ from ctypes import c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TUP_LIB_PATH") or os.path.join(_HERE, "libtupscale_hip.so")      # override: A/B of two builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 P = c_void_p
 I = c_int
@@ -79,6 +79,7 @@ SIGNATURES = {
     "tup_gemm_wgrad": [P, I, I, P, I, I, P, I, I, I, I, P],
     "tup_gemm_wgrad_bias": [P, I, I, P, I, I, P, I, P, I, I, I, P],
     "tup_patch_wgrad": [P, P, P, I, I, I, I, P],
+    "tup_patch_wgrad_bf16": [P, P, P, I, I, I, I, P],
     "tup_colsum": [P, I, I, P, I, I, P, P],
     "tup_layernorm_bwd": [P, P, P, P, P, P, P, P, P, I, P, F, U, P],
     "tup_relpos_bias_expand_n": [P, P, P],

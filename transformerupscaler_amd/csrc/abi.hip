@@ -1,2 +1,2 @@
 #include <hip/hip_runtime.h>
-extern "C" int tup_abi_version(void) { return 13; }
+extern "C" int tup_abi_version(void) { return 14; }

@@ -269,6 +269,215 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ G,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide-tile form for the two patch weights (NI = 192 or 128 token features x NJ = 4096 patch elements, M = every token).
+// gemm_wgrad_kernel above gives a workgroup a 64 x 64 output tile, so the fp32 token operand is fetched 64 times and the 472 MB
+// map three times: 4.5 GB through L2 per launch for 0.52 GB of operands, and the launch runs at that L2 rate (340 us).  Here
+// ONE workgroup per CU owns a 192 x (64 JP) tile -- all token features x JP patch pixels: the map is read once, the tokens
+// 4096 / (64 JP) times.  64-row stages of both operands go to LDS by DMA (global_load_lds; swizzle, patch gather, reflect /
+// zero padding and the ragged end of the M slice on the source side: no staging registers, which is what the 192-row form of
+// round 2 died of) into a ring of NST stages with one raw barrier per stage; NW = 4 or 8 waves, each (384 / NW) x (32 JP) of the
+// tile: per 32 rows of M a wave reads 24 / NW + 2 JP transposed fragments (asm, hand-counted lgkmcnt) for 48 JP / NW MFMAs.  The token operand must
+// be bf16 in memory (DMA does not convert).
+// Measured and NOT used for the Linear layers of the blocks (192 x {192, 576, 768}, JP = 3): the loop runs at 1.7 us per 48 KB
+// stage and CU (7 TB/s from cache-resident operands), but every workgroup ends with its whole tile as float atomics -- 256
+// workgroups x 36,864 = 9.4 M per launch whatever the layer, and the L2's atomic units take about one per clock and channel:
+// 36 us on top of a 7-26 us loop (43-63 us against 22-47 us for the 64 x 64 tiles, whose atomics hide behind the other
+// resident workgroups).  One image per XCD (no line migrating between L2s) + a reduce launch measured the same.  With M
+// slices of 7,680 rows (patch weights) the same epilogue is 10 % of the launch.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) unsigned int tup_wg_zero_line[4] = {0u, 0u, 0u, 0u};
+
+template <int JP, int NST, bool PATCH, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_wgrad_wide_kernel(const WgradParams p)
+{
+    constexpr int IP = 3;                              // 64-column panels of P per workgroup
+    constexpr int STAGE = (IP + JP) * 8192;            // a panel stage = 64 rows x 128 B
+    constexpr int RU = 8 / NW;                         // 32-row (NW = 4) or 64-row (NW = 8) groups of a stage per DMA instruction
+    constexpr int PER = (IP + JP) * RU;                // DMA instructions per thread and stage
+    constexpr int IT = 24 / NW;                        // 16-row tiles of the wave's i range: NW / 2 waves along i, two along j
+    constexpr int JT = 2 * JP;                         // 16-column tiles of the wave's j range
+    static_assert((NST - 2) * PER <= 63, "vmcnt field");
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int wi = wave % (NW / 2), wj = wave / (NW / 2);
+
+    const int nib = p.NI / 192, nij = nib * (p.NJ / (64 * JP));
+    const int T = gridDim.x, L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3, base = T >> 3, rem = T & 7;
+    const int Lp = xcd * base + min(xcd, rem) + slot;          // XCD k works through a contiguous range: same M slice = same L2
+    const int ij = Lp % nij, mz = Lp / nij;
+    const int i0 = (ij % nib) * 192, j0 = (ij / nib) * (64 * JP);
+    const int mbeg = mz * p.mchunk, mend = min(p.M, mbeg + p.mchunk);
+    if (mbeg >= mend) return;
+    const int nsteps = (mend - mbeg + 63) / 64;
+
+    // DMA bookkeeping: a thread moves chunk slot tid & 7 of rows (tid >> 3) and (tid >> 3) + 32 of every panel; the slot holds
+    // logical chunk dc (swz128's XOR, applied on the source side)
+    const int dr = tid >> 3, dc = (tid & 7) ^ ((tid >> 4) & 7);
+    const char* psrc = (const char*)p.P + ((size_t)i0 + dc * 8) * 2;
+    const char* qsrc = (const char*)p.Q + (PATCH ? (size_t)dc * 16 : ((size_t)j0 + dc * 8) * 2);
+    auto dma_stage = [&](int s, int buf) {
+        char* dst = dsm + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int m = mbeg + s * 64 + dr + 32 * u;
+            const bool ok = s < nsteps && m < mend;
+            const char* prow = psrc + (size_t)m * p.ldp * 2;
+#pragma unroll
+            for (int pn = 0; pn < IP; ++pn)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? prow + pn * 128 : (const char*)tup_wg_zero_line),
+                                                 (__attribute__((address_space(3))) void*)(dst + pn * 8192 + u * 4096), 16, 0, 0);
+            if constexpr (!PATCH) {
+                const char* qrow = qsrc + (size_t)m * p.ldq * 2;
+#pragma unroll
+                for (int pn = 0; pn < JP; ++pn)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? qrow + pn * 128 : (const char*)tup_wg_zero_line),
+                                                     (__attribute__((address_space(3))) void*)(dst + (IP + pn) * 8192 + u * 4096), 16, 0, 0);
+            } else {
+                // panel pn of the tile = patch pixel (j0 >> 6) + pn, 64 channels (see load_patch of the narrow kernel)
+                int b, ty, tx;
+                if (p.linear) {
+                    const int per = p.Ht * p.Wt_;
+                    b = m / per;
+                    const int r2 = m - b * per;
+                    ty = r2 / p.Wt_; tx = r2 - ty * p.Wt_;
+                } else {
+                    const int tok = m & 63;
+                    int win = m >> 6;
+                    const int wx = win % p.nWx; win /= p.nWx;
+                    const int wy = win % p.nWy;
+                    b = win / p.nWy;
+                    ty = wy * 8 + (tok >> 3); tx = wx * 8 + (tok & 7);
+                }
+                const bool tok_ok = ok && ty < p.Ht && tx < p.Wt_;
+#pragma unroll
+                for (int pn = 0; pn < JP; ++pn) {
+                    const int pix = (j0 >> 6) + pn;
+                    int py = ty * 8 + (pix >> 3), px = tx * 8 + (pix & 7);
+                    bool pok = tok_ok;
+                    if (p.reflect) {
+                        if (py >= p.H) py = 2 * p.H - 2 - py;
+                        if (px >= p.W) px = 2 * p.W - 2 - px;
+                    } else {
+                        pok = pok && py < p.H && px < p.W;
+                    }
+                    const char* src = pok ? qsrc + (((size_t)b * p.H + py) * p.W + px) * 128 : (const char*)tup_wg_zero_line;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(dst + (IP + pn) * 8192 + u * 4096), 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[IT][JT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_cs = p.colsum_out != nullptr && j0 == 0 && wj == 0;
+    f32x4 accs[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) accs[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
+
+    // transposed-read addressing (as above): lane 4q+pp of a 16-lane group supplies row q, columns 4pp..4pp+3 of a tile.
+    // The reads are asm statements (ds_read_b64_tr_b16, hand-counted lgkmcnt): behind a compiler-visible LDS read hipcc puts
+    // s_waitcnt vmcnt(0), i.e. a wait for the stages just requested.
+    const int trq = l16 >> 2, trp = l16 & 3;
+    auto frag_off = [&](int panel0, int col, int h) -> uint32_t {          // col = first column of the 16-wide tile in its panel group
+        const int c = col + 4 * trp, pn = panel0 + (c >> 6), pc = c & 63;
+        return (uint32_t)(pn * 8192 + (pc & 7) * 2 + swz128(8 * g + trq + 4 * h, pc >> 3));
+    };
+    uint32_t aoff[IT][2], boff[JT][2];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) { aoff[it][0] = frag_off(0, 16 * IT * wi + 16 * it, 0); aoff[it][1] = frag_off(0, 16 * IT * wi + 16 * it, 1); }
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) { boff[jt][0] = frag_off(IP, 32 * JP * wj + 16 * jt, 0); boff[jt][1] = frag_off(IP, 32 * JP * wj + 16 * jt, 1); }
+    auto rd = [](uint32_t addr, auto ksc) {
+        u32x2 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(decltype(ksc)::value * 4096));
+        return v;
+    };
+    auto join = [](u32x2 lo, u32x2 hi) { return __builtin_bit_cast(bf16x8, u32x4{lo[0], lo[1], hi[0], hi[1]}); };
+    const uint32_t lds0 = lds_addr(dsm);
+
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) dma_stage(s, s);
+    int buf = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        // own pieces of stage s, then everyone's; everyone is done with stage s - 1 (every LDS read of it was waited for).  A raw
+        // barrier: __syncthreads() carries a fence, which hipcc turns into vmcnt(0) -- a wait for the stages still in flight
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 2) * PER) : "memory");
+        dma_stage(s + NST - 1, buf == 0 ? NST - 1 : buf - 1);                         // into the buffer stage s - 1 used (past the end: zero lines)
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t sb = lds0 + (uint32_t)(buf * STAGE);
+        auto kstep = [&](auto ksc) {
+            u32x2 ar[IT][2], br[2][2];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) { ar[it][0] = rd(sb + aoff[it][0], ksc); ar[it][1] = rd(sb + aoff[it][1], ksc); }
+            br[0][0] = rd(sb + boff[0][0], ksc); br[0][1] = rd(sb + boff[0][1], ksc);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                if (jt + 1 < JT) {
+                    br[(jt + 1) & 1][0] = rd(sb + boff[jt + 1][0], ksc); br[(jt + 1) & 1][1] = rd(sb + boff[jt + 1][1], ksc);
+                    lds_wait<2>();
+                } else {
+                    lds_wait<0>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 bfr = join(br[jt & 1][0], br[jt & 1][1]);
+#pragma unroll
+                for (int it = 0; it < IT; ++it) acc[it][jt] = mfma16x16x32(join(ar[it][0], ar[it][1]), bfr, acc[it][jt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (want_cs) {
+#pragma unroll
+                for (int it = 0; it < IT; ++it) accs[it] = mfma16x16x32(join(ar[it][0], ar[it][1]), ones, accs[it]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(std::integral_constant<int, 0>{});
+        kstep(std::integral_constant<int, 1>{});
+        buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the zero-line requests past the end
+
+    // D[row = i 4g+e][col = j l16]
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(p.out + (size_t)(i0 + 16 * IT * wi + 16 * it + 4 * g + e) * p.ldo + j0 + 32 * JP * wj + 16 * jt + l16, acc[it][jt][e]);
+    if (want_cs && l16 == 0) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(p.colsum_out + i0 + 16 * IT * wi + 16 * it + 4 * g + e, accs[it][e]);
+    }
+}
+
+template <int JP, int NST, bool PATCH, int NW>
+int launch_wide(WgradParams p, hipStream_t s)
+{
+    if (p.M <= 0) return 0;
+    if (p.NI % 192 || p.NJ % (64 * JP)) return (int)hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)NST * (3 + JP) * 8192;
+    TUP_SET_DYN_LDS((gemm_wgrad_wide_kernel<JP, NST, PATCH, NW>), lds);
+    const int nij = (p.NI / 192) * (p.NJ / (64 * JP));
+    // one workgroup per CU (the LDS ring); M slices of whole 64-row stages
+    int msplit = 256 / nij;
+    if (msplit < 1) msplit = 1;
+    p.mchunk = (((p.M + msplit - 1) / msplit) + 63) / 64 * 64;
+    msplit = (p.M + p.mchunk - 1) / p.mchunk;
+    gemm_wgrad_wide_kernel<JP, NST, PATCH, NW><<<dim3(nij * msplit), dim3(64 * NW), lds, s>>>(p);
+    TUP_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int PMODE, int QMODE>
 int launch(WgradParams p, hipStream_t s)
 {
@@ -331,6 +540,30 @@ extern "C" int tup_patch_wgrad(const float* P, const void* map, float* out, int 
     p.P = P; p.ldp = 192; p.Q = map; p.out = out; p.ldo = 4096;
     p.M = B * p.nWy * p.nWx * 64; p.NI = 192; p.NJ = 4096;
     return launch<OP_F32, OP_PATCH>(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+// The same from bf16 token rows (P bf16 [M][192]: the rounding the fp32 form applies on load, done by the caller) on the wide-tile
+// kernel: one pass over the map.
+extern "C" int tup_patch_wgrad_bf16(const void* P, const void* map, float* out, int B, int H, int W, int reflect, void* stream)
+{
+    WgradParams p{};
+    p.H = H; p.W = W; p.Ht = (H + 7) / 8; p.Wt_ = (W + 7) / 8;
+    p.nWy = (p.Ht + 7) / 8; p.nWx = (p.Wt_ + 7) / 8; p.reflect = reflect;
+    p.P = P; p.ldp = 192; p.Q = map; p.out = out; p.ldo = 4096;
+    p.M = B * p.nWy * p.nWx * 64; p.NI = 192; p.NJ = 4096;
+    if ((long long)B * H * W * 128 >= (1LL << 31)) return (int)hipErrorInvalidValue;          // 32-bit pixel offsets in the gather
+    static const int form = TUP_ENV_INT("TUP_PATCH_WGRAD_FORM", 0);          // tuning knob (diagnostic build)
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // 4 x 720p, incl. the zero fill and the caller's bf16 cast (64 x 64 tiles: 350-390 us): 192 x 256 tile / 2 stages / 8 waves
+    // 177-182 us; 192 x 128 / 3 stages / 8 waves 194-214; 192 x 256 / 2 / 4 waves 260-280; 192 x 128 / 3 / 4 waves 285-300 -- one wave
+    // per SIMD hides neither its gather arithmetic nor its LDS waits
+#ifdef TUP_DIAG          // the other forms exist in `make diag` only
+    if (form == 1) return launch_wide<2, 3, true, 4>(p, st);
+    if (form == 2) return launch_wide<4, 2, true, 4>(p, st);
+    if (form == 3) return launch_wide<2, 3, true, 8>(p, st);
+#endif
+    (void)form;
+    return launch_wide<4, 2, true, 8>(p, st);
 }
 
 // ResidualTransformer's patch_embed / patch_unembed weights: out[128][4096] += P^T patches(map), P fp32 [B*T][128]

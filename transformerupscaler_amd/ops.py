@@ -509,10 +509,19 @@ def gemm_wgrad_bias(p, q):
     return out, db
 
 
+PATCH_WGRAD_WIDE = True          # A/B switch: the wide-tile kernel (tup_patch_wgrad_bf16) for the two patch weights
+
+
 def patch_wgrad(p, fmap, reflect):
     B, H, W, C = fmap.shape
     _, _, nwy, nwx = window_geometry(H, W)
     out = _zeros((192, 4096), p.device)
+    if PATCH_WGRAD_WIDE and B * H * W * 128 < 2 ** 31:
+        # bf16 token rows (the rounding the fp32 entry applies on load): the wide kernel fetches its operands by DMA
+        _chk(p, F32, (B * nwy * nwx * 64, 192), "p")
+        pb = p.to(BF16)
+        _lib.call("tup_patch_wgrad_bf16", pb.data_ptr(), _chk(fmap, BF16, None, "map"), out.data_ptr(), B, H, W, int(reflect), _stream())
+        return out
     _lib.call("tup_patch_wgrad", _chk(p, F32, (B * nwy * nwx * 64, 192), "p"), _chk(fmap, BF16, None, "map"),
               out.data_ptr(), B, H, W, int(reflect), _stream())
     return out

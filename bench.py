@@ -618,6 +618,11 @@ def main():
                  "algorithmic_flop_per_launch": CONV64_FLOP_PER_IMAGE * args.batch,
                  "algorithmic_bytes": 2 * args.batch * LR_H * LR_W * 64 * 2,
                  "ms_per_launch": conv_ms, "total_ms_per_forward": 2 * conv_ms, "launches_timed": len(events)}
+    # the same launch against the HBM roof (8 TB/s, MI355X_MICROARCH.md): by the ablations of DESIGN 5c its memory side alone (DMA + stores,
+    # no K loop) takes 85 % of the kernel's time, i.e. the launch sits nearer this roof than the MFMA one
+    conv_gbps = roof_conv["algorithmic_bytes"] / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+    roof_conv["hbm"] = {"achieved": conv_gbps, "peak": 8000.0, "unit": "GB/s", "frac": conv_gbps / 8000.0,
+                        "note": "algorithmic bytes (one read + one write of the 64-channel bf16 map) / the same launch time"}
     dominant, second = (roof_block, roof_conv) if blocks_ms >= 2 * conv_ms else (roof_conv, roof_block)
 
     if rank == 0:

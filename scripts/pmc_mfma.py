@@ -31,6 +31,8 @@ KERNELS_BY_MODE = {
         "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip"),
         "gemm_wgrad": ("gemm_wgrad_kernel<0, 0>", "gemm_wgrad.hip"),
         "bra_wgrad": ("bra_wgrad_kernel", "branch_a_train.hip"),
+        "conv_thin_wgrad": ("conv3x3_wgrad_thin_kernel", "conv_bwd.hip"),
+        "patch_wgrad_wide": ("gemm_wgrad_wide_kernel<4, 2, true, 8>", "gemm_wgrad.hip"),
         "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip"),
         "window_attn_fwd": ("window_attn_kernel<12", "attention.hip"),
         "fused_mlp": ("fused_mlp_v2_kernel", "fused_blocks.hip"),

@@ -36,6 +36,9 @@ KEYS = {
         "window_attn_bwd": ("window_attn_bwd_kernel<12>", "attention_bwd.hip", 960 * 64 * (576 * 2 + 2 * 192 * 2 + 576 * 2) + 960 * 12 * 64 * 4),      # qkv, d att, att, lse in; d qkv out
         "conv64": ("conv_c64_persistent_kernel<4, 0, 3>", "conv3x3_c64.hip", 2 * 4 * F64),
         "conv64_wgrad": ("conv3x3_wgrad_c64_kernel", "conv_bwd.hip", 2 * 4 * F64),
+        "conv_thin_wgrad": ("conv3x3_wgrad_thin_kernel", "conv_bwd.hip", 4 * F64 + 4 * 3 * 720 * 1280 * 4),                 # the 64-channel map + the 3-channel fp32 gradient
+        "bra_wgrad": ("bra_wgrad_kernel", "branch_a_train.hip", 4 * F64 + 4 * 720 * 1280 * 16 * 2),                         # feat + g12 (16 bf16 per pixel)
+        "patch_wgrad_wide": ("gemm_wgrad_wide_kernel<4, 2, true, 8>", "gemm_wgrad.hip", 4 * F64 + 960 * 64 * 192 * 2 + 192 * 4096 * 4),     # the map once, the bf16 token rows once, the fp32 output
         "feat_grad_combine": ("feat_grad_combine_kernel", "conv_bwd.hip", 5 * 4 * F64),          # only when H or W is not a multiple of 8
         "pe_bwd_merge": ("gemm_panel2_kernel<1, 6>", "gemm_tokens.hip", 960 * 64 * 192 * 4 + 4 * 4 * F64),      # tokens in; two adds, the gate map in, the merged gradient out
     },

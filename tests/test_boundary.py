@@ -317,3 +317,42 @@ def test_rt_attention_dropout_on_an_unsupported_token_count_raises_a_clear_error
         ops.rt_attention(torch.empty((2 * 506, 384), dtype=torch.bfloat16), 2, 506, drop_p=0.1)
     with pytest.raises(ValueError, match="multiple of 4"):
         ops.rt_attention_bwd(None, None, None, None, 1, 22 * 23, drop_p=0.1)
+
+
+def test_halo_row_read_addresses_of_the_weight_gradient_kernels():
+    """The conv / branch-A weight-gradient kernels (csrc/conv_bwd.hip, csrc/branch_a_train.hip) read their transposed X fragments at
+    `xb0 + ((xc ^ ((xs + k * hy) & 7)) << 4) + hy * row_bytes` -- lane constants + the halo row -- instead of swz128(q, chunk) of the pixel
+    index.  Restated here for every lane, tap column and halo row against common.h's swz128, with the divisions by the halo width the
+    kernels replace by a multiply-shift, and with the source-side swizzle of the DMA pieces of the wide weight-gradient kernel."""
+    def swz128(row, chunk):
+        return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)
+
+    for halo_w, halo_h, ndx, k in ((34, 10, 3, 1), (36, 12, 5, 2)):          # 3x3 convs; the composed 5x5 branch A
+        assert halo_w % 2 == 0 and (halo_w // 2) % 8 == k % 8                  # a halo row shifts the swizzle phase by k
+        for lane in range(64):
+            g, l16 = lane >> 4, lane & 15
+            trq, trp = l16 >> 2, l16 & 3
+            for cit in range(4):
+                xcol = 16 * cit + 4 * trp
+                xc = xcol >> 3
+                for dx in range(ndx):
+                    for h in range(2):
+                        q0 = 8 * g + trq + dx + 4 * h
+                        xs, xb0 = q0 >> 1, q0 * 128 + (xcol & 7) * 2
+                        for hy in range(halo_h):
+                            got = xb0 + ((xc ^ ((xs + k * hy) & 7)) << 4) + hy * halo_w * 128
+                            q = hy * halo_w + q0
+                            assert got == swz128(q, xcol >> 3) + (xcol & 7) * 2, (halo_w, lane, cit, dx, h, hy)
+    # G tiles are 32 pixels wide: the phase of pixel ry * 32 + 8g + trq + 4h does not depend on the row
+    for ry in range(8):
+        for p in range(32):
+            assert ((ry * 32 + p) >> 1) & 7 == (p >> 1) & 7
+    assert all((q * 241) >> 13 == q // 34 for q in range(340))
+    assert all((q * 911) >> 15 == q // 36 for q in range(432))
+    # gemm_wgrad_wide_kernel: thread tid moves physical slot tid & 7 of row (tid >> 3) (+ 32): it must fetch logical chunk
+    # dc = slot ^ ((row >> 1) & 7), so that a fragment read at swz128(row, chunk) finds chunk `chunk`
+    for tid in range(512):
+        row, slot = tid >> 3, tid & 7
+        dc = slot ^ ((tid >> 4) & 7)
+        assert swz128(row, dc) == row * 128 + slot * 16
+        assert swz128(row + 32, dc) == (row + 32) * 128 + slot * 16           # the second row of a 256-thread workgroup

@@ -28,6 +28,9 @@ GUARDED = [
     # no counted hand-off here: guarded because the unrolled halo-row loops sit at 240 / 202 registers and a build that hoists their
     # read addresses out of the tile loop spills (seen twice while they were written)
     ("conv_bwd.hip", ["conv3x3_wgrad_c64_kernel", "conv3x3_wgrad_thin_kernel"]),
+    ("branch_a_train.hip", ["bra_wgrad_kernel"]),
+    # counted vmcnt between its LDS-DMA stages, asm fragment reads with counted lgkmcnt
+    ("gemm_wgrad.hip", ["gemm_wgrad_wide_kernel"]),
 ]
 # diagnostic template instantiations, never launched by the product path: fused_qkv_attn_kernel<PROJ, MLP, STAMPS = true>, the
 # timing ablations fused_mlp_v2_kernel<ABL != 0>
